@@ -1,0 +1,240 @@
+/*
+ * rt_abi.h — C ABI of the MI355X-native ray-trace hot path (librt_amd.so).
+ *
+ * This is the drop-in boundary for the per-pixel path of someguynamedjosh/raytrace:
+ * what the reference does in shaders/glsl/raytrace.comp behind `render::Pipeline`
+ * is done here by hand-written gfx950 HIP kernels behind plain `extern "C"` entry
+ * points (plain pointers and sizes only; no C++/torch types cross this line).
+ * A Rust host binds these with an `extern "C"` block.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to
+ * the reference repository root).
+ *
+ * Conventions
+ *   - All functions returning int return RT_OK (0) or a negative RtStatus; they
+ *     never throw or abort (the reference panics via .expect(): pipeline.rs:145,167).
+ *   - Host pointers are borrowed for the duration of the call only; the context
+ *     owns all device memory (reference: Vulkan objects owned by RenderData).
+ *   - A context is used from one host thread at a time (reference: Rc<Core> is !Send,
+ *     render/mod.rs:40).
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants restated from src/render/constants.rs:15-33 and raytrace.comp:37-58 ---- */
+#define RT_CHUNK_SIZE        64      /* constants.rs:23  CHUNK_SIZE = 1 << MAX_CHUNK_LOD      */
+#define RT_MAX_CHUNK_LOD     6       /* constants.rs:22                                       */
+#define RT_ROOT_CHUNK_SIZE   4       /* constants.rs:26                                       */
+#define RT_ROOT_BLOCK_SIZE   256     /* constants.rs:27; raytrace.comp:37 ROOT_BLOCK_WIDTH    */
+#define RT_SLICE_SIZE        16      /* constants.rs:30                                       */
+#define RT_SHADER_GROUP_SIZE 8       /* constants.rs:33; raytrace.comp:9 local_size 8x8       */
+#define RT_PIXEL_SPREAD      16      /* raytrace.comp:54                                      */
+#define RT_NOISE_SIZE        512     /* constants.rs:16-17; raytrace.comp:43                  */
+#define RT_NOISE_BYTES       (512 * 512 * 4) /* constants.rs:19 BLUE_NOISE_SIZE               */
+#define RT_LIGHTING_SCALE    16.0f   /* raytrace.comp:57                                      */
+#define RT_TRACE_LIMIT       2048    /* raytrace.comp:109                                     */
+#define RT_NORMAL_AIR        16      /* raytrace.comp:369 value stored for sky pixels         */
+#define RT_DEPTH_AIR         0xFFFF  /* raytrace.comp:357                                     */
+#define RT_MAX_DEPTH         16      /* build limit on the `depth` extension      */
+
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,
+    RT_ERR_NO_DEVICE = -2,      /* no HIP device / HIP runtime failure at create          */
+    RT_ERR_HIP = -3,            /* a HIP call failed; see rt_last_error                   */
+    RT_ERR_NOT_READY = -4,      /* draw before world/noise upload                         */
+    RT_ERR_UNIMPLEMENTED = -5,
+    RT_ERR_OOM = -6
+} RtStatus;
+
+/*
+ * RtUniforms — byte-identical to `RaytraceUniformData` (src/render/pipeline/structs.rs:3-31)
+ * and the GLSL std140 block `UniformData` (shaders/glsl/raytrace.comp:25-35). 192 bytes.
+ * Live fields: sun_angle@0 seed@4 origin@16 forward@32 up@48 right@64 lr@160.
+ * Dead in the shader (kept for layout): old_origin@80 old_transform_c0..2@96/112/128
+ * region_offset@144 lso@176.
+ */
+typedef struct RtUniforms {
+    float    sun_angle;           /*   0 */
+    uint32_t seed;                /*   4 */
+    uint32_t _padding0[2];        /*   8  (u64 in the reference)                       */
+    float    origin[3];           /*  16 */
+    uint32_t _padding1;
+    float    forward[3];          /*  32 */
+    uint32_t _padding2;
+    float    up[3];               /*  48  pre-scaled by 0.4 on the host: pipeline.rs:198 */
+    uint32_t _padding3;
+    float    right[3];            /*  64  pre-scaled by 0.4 on the host: pipeline.rs:199 */
+    uint32_t _padding4;
+    float    old_origin[3];       /*  80  dead */
+    uint32_t _padding5;
+    float    old_transform_c0[3]; /*  96  dead */
+    uint32_t _padding6;
+    float    old_transform_c1[3]; /* 112  dead */
+    uint32_t _padding7;
+    float    old_transform_c2[3]; /* 128  dead */
+    uint32_t _padding8;
+    int32_t  region_offset[3];    /* 144  dead */
+    uint32_t _padding9;
+    int32_t  lr[3];               /* 160  `rotation` in structs.rs:27; `lr` in the shader */
+    uint32_t _padding10;
+    int32_t  lso[3];              /* 176  `space_offset`; dead */
+    uint32_t _padding11;
+} RtUniforms;
+
+/* Which traversal implementation a context uses. */
+typedef enum RtKernel {
+    RT_KERNEL_DEFAULT = 0,   /* library picks (wavefront)                                           */
+    RT_KERNEL_MEGA = 1,      /* one thread per pixel, all rays inline, byte minefield from HBM      */
+    RT_KERNEL_WAVEFRONT = 2  /* persistent wave64 traversal, ballot refill, LDS brick map, SoA rays */
+} RtKernel;
+
+#define RT_FLAG_COUNTERS      0x1u  /* count rays/iterations/hits exactly (slower; for B_alg + parity)   */
+#define RT_FLAG_CACHE_PRIMARY 0x2u  /* spp>1: trace the (seed-independent) primary ray once per pixel    */
+#define RT_FLAG_TIMING        0x4u  /* bracket every kernel launch with HIP events (rt_get_timing detail)  */
+
+/*
+ * RtConfig — replaces the compile-time window constants (constants.rs:9-10) and adds the
+ * build's extensions: spp, depth, and the multi-GPU tile split.
+ *   spp = N   : N frames with seed, seed+1, ... (mod RT_NOISE_BYTES, pipeline.rs:201);
+ *               lighting = (sum_i light_i) / N in fp32; other planes from the primary hit.
+ *   depth = D : light recursion truncated at D levels; D=2 is exactly raytrace.comp:321-350.
+ *   tile_rank/tile_world : this context renders only the 8x8-pixel tiles t with
+ *               t % tile_world == tile_rank (t = row-major tile index); outputs are then
+ *               tile-major (see rt_tile_count / rt_untile).  tile_world=1 => whole frame,
+ *               row-major pixel layout, row 0 = bottom of the view (finalize.comp:60-63).
+ */
+typedef struct RtConfig {
+    uint32_t struct_size;   /* sizeof(RtConfig), for forward compatibility */
+    int32_t  width;
+    int32_t  height;
+    int32_t  region;        /* must be RT_ROOT_BLOCK_SIZE (256) in this version */
+    int32_t  spp;           /* >= 1 */
+    int32_t  depth;         /* 0..RT_MAX_DEPTH */
+    int32_t  device;        /* HIP device ordinal */
+    int32_t  tile_rank;
+    int32_t  tile_world;
+    int32_t  kernel;        /* RtKernel */
+    uint32_t flags;         /* RT_FLAG_* */
+    int32_t  reserved[5];
+} RtConfig;
+
+/* Output planes. Bindings cited from shaders/glsl/raytrace.comp:14-21; formats from
+ * src/render/pipeline/render_data.rs:166-189. */
+typedef enum RtBufferId {
+    RT_BUF_LIGHTING_RGBA16 = 0, /* binding 5, R16G16B16A16_UNORM: vec4(light,1)/16            8 B/px */
+    RT_BUF_DEPTH_R16UI     = 1, /* binding 8, R16_UINT: uint(|origin-pos|*32) or 0xFFFF       2 B/px */
+    RT_BUF_NORMAL_R8UI     = 2, /* binding 7, R8_UINT: face id 0..5 or 16                     1 B/px */
+    RT_BUF_ALBEDO_RGBA8    = 3, /* binding 2, RGBA8_UNORM                                     4 B/px */
+    RT_BUF_EMISSION_RGBA8  = 4, /* binding 3, RGBA8_UNORM                                     4 B/px */
+    RT_BUF_FOG_RGBA8       = 5, /* binding 4, RGBA8_UNORM: sky(dir, no sun)/2                 4 B/px */
+    RT_BUF_LIGHTING_F32    = 6, /* the vec4 handed to imageStore before UNORM conversion      16 B/px */
+    RT_BUF_FOG_F32         = 7, /* same for fog                                               16 B/px */
+    RT_BUF_DEPTH_F32       = 8, /* |origin-pos|*32 before uint(); 65535.0 for sky             4 B/px */
+    RT_BUF_COUNT           = 9
+} RtBufferId;
+
+/* Exact integer counters (RT_FLAG_COUNTERS), accumulated since the last rt_reset_counters.
+ * B_alg = minefield_fetches*1 + material_fetches*4 + noise_fetches*4 + pixels*23. */
+typedef struct RtCounters {
+    uint64_t rays;               /* trace_ray invocations (primary + shadow + diffuse)     */
+    uint64_t rays_primary;
+    uint64_t rays_shadow;
+    uint64_t rays_diffuse;
+    uint64_t iterations;         /* DDA loop iterations (raytrace.comp:113)                */
+    uint64_t minefield_fetches;  /* = rays + iterations (raytrace.comp:106,137)            */
+    uint64_t material_fetches;   /* = hits (raytrace.comp:150-154)                         */
+    uint64_t noise_fetches;      /* noise_value + seed-base lookups (raytrace.comp:302-303,324,336) */
+    uint64_t hits;
+    uint64_t sky_exits;
+    uint64_t limit_exits;        /* Q8: loop limit reached                                 */
+    uint64_t border_fetches;     /* Q7: minefield fetch outside [0,256)^3 or NaN -> 0      */
+    uint64_t pixels;             /* output pixels written (x frames)                       */
+    uint64_t frames;
+} RtCounters;
+
+/* HIP-event timings of the last rt_draw_frame (valid after rt_sync), milliseconds. */
+typedef struct RtTiming {
+    float    frame_ms;        /* whole frame on the context's stream                      */
+    float    trace_ms;        /* sum of traversal-kernel launches                         */
+    float    shade_ms;        /* sum of ray-gen / shade / resolve launches                */
+    uint32_t trace_launches;
+    uint32_t other_launches;
+    uint64_t rays_traced;     /* rays pushed through the traversal kernel this frame      */
+} RtTiming;
+
+typedef struct RtContext RtContext;
+
+/* render::create_instance (src/render/mod.rs:36-43) + Pipeline::new (pipeline.rs:36-76):
+ * create device resources for one GPU. *out is NULL on failure; rt_last_error(NULL) explains. */
+int rt_create(const RtConfig* cfg, RtContext** out);
+
+/* impl Drop for Pipeline (pipeline.rs:258-277): wait idle, free everything. NULL is a no-op. */
+void rt_destroy(RtContext* ctx);
+
+/* Message for the last failure on this context (or the last rt_create failure on this thread
+ * when ctx is NULL). Never NULL. */
+const char* rt_last_error(RtContext* ctx);
+
+/* RenderData::initialize -> full-region upload (render_data.rs:269-301; formats :54-108).
+ * materials: u32[256^3], minefield: u8[256^3], both x-fastest (util.rs:104-106), texel = world+128
+ * (render_data.rs:221-236). The library re-tiles into 4^3 bricks on the device. */
+int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* minefield);
+
+/* TerrainUploadManager::upload_slice (terrain_upload.rs:84-275) -> vkCmdCopyBufferToImage with an
+ * offset (command_buffer.rs:262-298): replace one 16-thick slab of the region.  axis 0/1/2 = x/y/z;
+ * texel_offset (multiple of 16, < 256) is the slab's start along that axis; the data is a dense box of
+ * extent (16,256,256) / (256,16,256) / (256,256,16), x fastest (terrain_upload.rs:96-100). */
+int rt_upload_slice(RtContext* ctx, int axis, int texel_offset,
+                    const uint32_t* materials, const uint8_t* minefield);
+
+/* Blue-noise table (render_data.rs:110-133; decoded by structures.rs:496-517): RGBA8 512x512. */
+int rt_upload_noise(RtContext* ctx, const uint8_t* rgba8);
+
+/* UBO write + queue submit of the raytrace dispatch (pipeline.rs:195-211,229-235; dispatch :86-90).
+ * Asynchronous: returns after enqueue on the context's stream. */
+int rt_draw_frame(RtContext* ctx, const RtUniforms* uniforms);
+
+/* Fence wait (pipeline.rs:162-172). */
+int rt_sync(RtContext* ctx);
+
+/* Copy an output plane to host memory (synchronises first). bytes must equal rt_buffer_bytes. */
+int rt_readback(RtContext* ctx, int buffer_id, void* dst, size_t bytes);
+
+/* Size in bytes of an output plane for this context (tile-major planes are padded to whole tiles). */
+size_t rt_buffer_bytes(RtContext* ctx, int buffer_id);
+
+/* Device pointer of an output plane for zero-copy consumers (denoise/finalize, RCCL gather);
+ * the images bound at descriptor_sets.rs:64-84. NULL on bad id. */
+void* rt_device_ptr(RtContext* ctx, int buffer_id);
+
+/* Run on a caller-provided hipStream_t (NULL = the context's own stream). */
+int rt_set_stream(RtContext* ctx, void* hip_stream);
+
+/* Multi-GPU tile split: number of 8x8 tiles this context renders, and the padded
+ * per-rank tile capacity ceil(total_tiles / tile_world) used for equal-size gathers. */
+int rt_tile_count(RtContext* ctx);
+int rt_tile_capacity(RtContext* ctx);
+
+/* Scatter `world` gathered tile-major planes (rank-major: world x capacity x 64 px x bpp, device
+ * memory) into a row-major full-frame plane (device memory) on this context's stream. */
+int rt_untile(RtContext* ctx, int buffer_id, const void* gathered_dev, int world, void* frame_dev);
+
+int rt_get_counters(RtContext* ctx, RtCounters* out);
+int rt_reset_counters(RtContext* ctx);
+int rt_get_timing(RtContext* ctx, RtTiming* out);
+
+/* Library/ABI version: (major<<16)|minor. */
+uint32_t rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,504 @@
+// rt_api.hip — implementation of the C ABI in include/rt_abi.h on top of the kernels in rt_kernels.hip.
+//
+// One context = one GPU = one HIP stream.  Nothing here runs ray-trace work on the CPU: if the HIP runtime or a
+// device is missing, rt_create fails with RT_ERR_NO_DEVICE and the caller gets no context.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "../../include/rt_math.h"
+#include "rt_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+constexpr int kR = RT_ROOT_BLOCK_SIZE;
+constexpr size_t kVox = (size_t)kR * kR * kR;
+
+const size_t kBytesPerPixel[RT_BUF_COUNT] = {8, 2, 1, 4, 4, 4, 16, 16, 4};
+
+}  // namespace
+
+struct RtContext {
+    RtConfig cfg{};
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err = "";
+    bool has_world = false, has_noise = false;
+
+    // scene
+    uint8_t* d_mine_lin = nullptr; uint32_t* d_mat_lin = nullptr;
+    uint8_t* d_mine_sw = nullptr; uint32_t* d_mat_sw = nullptr;
+    uint32_t* d_coarse = nullptr; uint32_t* d_noise = nullptr; uint32_t* d_flag = nullptr;
+
+    // tiling
+    int tiles_x = 0, tiles_y = 0, ntiles_total = 0, ntiles_local = 0, tile_capacity = 0;
+    uint32_t npix_pad = 0;     // ntiles_local * 64
+    size_t plane_pixels = 0;   // pixels per output plane
+
+    void* planes[RT_BUF_COUNT] = {};
+
+    // wavefront pipeline state
+    int kernel = RT_KERNEL_WAVEFRONT;
+    uint32_t batch_samples = 1;   // samples per batch
+    uint32_t cap = 0;             // paths per batch (allocation)
+    uint32_t refill_threshold = 24;
+    float *qox = nullptr, *qoy = nullptr, *qoz = nullptr, *qdx = nullptr, *qdy = nullptr, *qdz = nullptr;
+    uint32_t* qid = nullptr;
+    float *hx = nullptr, *hy = nullptr, *hz = nullptr;
+    uint32_t* hinfo = nullptr;
+    uint8_t *sunres = nullptr, *pnormal = nullptr, *pstate = nullptr;
+    float *pdx = nullptr, *pdy = nullptr, *pdz = nullptr, *plx = nullptr, *ply = nullptr, *plz = nullptr;
+    uint32_t *sunbits = nullptr, *stack = nullptr;
+    float4* acc = nullptr;
+    uint32_t* ctrl = nullptr;     // per batch: [RT_MAX_DEPTH+2] pair counts, then [RT_MAX_DEPTH+2] cursors
+    rtd::DevCounters* d_counters = nullptr;
+    uint64_t host_noise_base = 0, host_frames = 0;
+
+    // timing
+    hipEvent_t ev_frame0 = nullptr, ev_frame1 = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_kind;     // per (start,stop) pair: 0 = trace, 1 = other
+    size_t ev_used = 0;
+    bool frame_recorded = false;
+    uint64_t rays_bound = 0;
+
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+int fail(RtContext* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,                     \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                           \
+    } while (0)
+
+template <typename T>
+hipError_t dev_alloc(RtContext* c, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e == hipSuccess) c->allocs.push_back((void*)*p);
+    return e;
+}
+
+rtd::Scene scene_of(const RtContext* c) {
+    rtd::Scene s;
+    s.mine = c->d_mine_sw; s.mat = c->d_mat_sw; s.coarse = c->d_coarse; s.noise = c->d_noise;
+    return s;
+}
+
+rtd::Planes planes_of(const RtContext* c) {
+    rtd::Planes p;
+    p.lighting_rgba16 = (uint16_t*)c->planes[RT_BUF_LIGHTING_RGBA16];
+    p.depth_r16 = (uint16_t*)c->planes[RT_BUF_DEPTH_R16UI];
+    p.normal_r8 = (uint8_t*)c->planes[RT_BUF_NORMAL_R8UI];
+    p.albedo_rgba8 = (uint32_t*)c->planes[RT_BUF_ALBEDO_RGBA8];
+    p.emission_rgba8 = (uint32_t*)c->planes[RT_BUF_EMISSION_RGBA8];
+    p.fog_rgba8 = (uint32_t*)c->planes[RT_BUF_FOG_RGBA8];
+    p.lighting_f32 = (float*)c->planes[RT_BUF_LIGHTING_F32];
+    p.fog_f32 = (float*)c->planes[RT_BUF_FOG_F32];
+    p.depth_f32 = (float*)c->planes[RT_BUF_DEPTH_F32];
+    return p;
+}
+
+// raytrace.comp:317-318 — uniform over the frame, so evaluated once here with the same rt_math.h the kernels use.
+void sun_constants(float a, float* sunangle, float* sunlight) {
+    float s, c;
+    rtm_sincos(a, &s, &c);
+    rtm_vec3 v = rtm_normalize3({c * 0.5f + (a - 0.5f) * 0.5f, s, c});
+    sunangle[0] = v.x; sunangle[1] = v.y; sunangle[2] = v.z;
+    // sun_color, raytrace.comp:259-269
+    float horizon = rtm_length2(v.x, v.y);
+    float sun_amount = rtm_min(1.0f - horizon, 0.02f) * 50.0f;
+    const float main_color[3] = {0.9647f * 2.0f, 0.7843f * 2.0f, 0.8824f * 2.0f};
+    const float sunset_color[3] = {0.7412f * 2.0f, 0.2157f * 2.0f, 0.1686f * 2.0f};
+    for (int k = 0; k < 3; k++)
+        sunlight[k] = v.z >= 0.0f ? rtm_mix(sunset_color[k], main_color[k], sun_amount)
+                                  : rtm_mix(sunset_color[k], 0.0f, sun_amount * 2);
+}
+
+rtd::Frame frame_of(const RtContext* c, const RtUniforms* u) {
+    rtd::Frame f;
+    for (int k = 0; k < 3; k++) {
+        f.origin[k] = u->origin[k]; f.forward[k] = u->forward[k]; f.up[k] = u->up[k]; f.right[k] = u->right[k];
+        f.lr[k] = (float)u->lr[k];    // vec3 current_rotation = uniform_data.lr (raytrace.comp:104)
+    }
+    sun_constants(u->sun_angle, f.sunangle, f.sunlight);
+    f.seed = u->seed;
+    f.width = c->cfg.width; f.height = c->cfg.height;
+    f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y;
+    f.tile_rank = c->cfg.tile_rank; f.tile_world = c->cfg.tile_world;
+    f.ntiles_local = c->ntiles_local;
+    f.spp = c->cfg.spp; f.depth = c->cfg.depth;
+    f.lr_zero = (u->lr[0] == 0 && u->lr[1] == 0 && u->lr[2] == 0) ? 1 : 0;
+    return f;
+}
+
+// Event pair bracketing one launch (only with RT_FLAG_TIMING).
+struct LaunchTimer {
+    RtContext* c; bool on; size_t idx;
+    LaunchTimer(RtContext* ctx, int kind) : c(ctx), on((ctx->cfg.flags & RT_FLAG_TIMING) != 0), idx(0) {
+        if (!on) return;
+        if (c->ev_used + 2 > c->ev_pool.size()) {
+            for (int k = 0; k < 2; k++) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } c->ev_pool.push_back(e); }
+        }
+        idx = c->ev_used; c->ev_used += 2;
+        if (c->ev_kind.size() < c->ev_used / 2) c->ev_kind.resize(c->ev_used / 2);
+        c->ev_kind[idx / 2] = kind;
+        (void)hipEventRecord(c->ev_pool[idx], c->stream);
+    }
+    ~LaunchTimer() { if (on) (void)hipEventRecord(c->ev_pool[idx + 1], c->stream); }
+};
+
+int reflatten(RtContext* c) {
+    RT_HIP(c, hipMemsetAsync(c->d_flag, 0, sizeof(uint32_t), c->stream));
+    RT_HIP(c, rtd::launch_flatten(c->d_mine_lin, c->d_mat_lin, c->d_mine_sw, c->d_mat_sw, c->d_coarse, c->d_flag, c->stream));
+    uint32_t flag = 0;
+    RT_HIP(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (flag) return fail(c, RT_ERR_INVALID_ARG, "minefield holds a value above 30 (the reference writes 0..6, src/world/chunk.rs:163-183)");
+    return RT_OK;
+}
+
+int draw_wavefront(RtContext* c, const rtd::Frame& f) {
+    const bool count = (c->cfg.flags & RT_FLAG_COUNTERS) != 0;
+    const rtd::Scene sc = scene_of(c);
+    const rtd::Planes pl = planes_of(c);
+    const int D = c->cfg.depth;
+    const uint32_t spp = (uint32_t)c->cfg.spp;
+    const uint32_t B = c->batch_samples;
+    const uint32_t ctrl_words = 2 * (RT_MAX_DEPTH + 2);
+    uint32_t batch = 0;
+    for (uint32_t s0 = 0; s0 < spp; s0 += B, batch++) {
+        const uint32_t ns = spp - s0 < B ? spp - s0 : B;
+        const uint32_t npaths = c->npix_pad * ns;
+        uint32_t* counts = c->ctrl;
+        uint32_t* cursors = c->ctrl + (RT_MAX_DEPTH + 2);
+        RT_HIP(c, hipMemsetAsync(c->ctrl, 0, ctrl_words * sizeof(uint32_t), c->stream));
+
+        rtd::TraceArgs ta{};
+        ta.qox = c->qox; ta.qoy = c->qoy; ta.qoz = c->qoz; ta.qdx = c->qdx; ta.qdy = c->qdy; ta.qdz = c->qdz; ta.qid = c->qid;
+        ta.qcap = c->cap; ta.nprimary = npaths; ta.npix_pad = c->npix_pad; ta.refill_threshold = c->refill_threshold;
+        ta.hx = c->hx; ta.hy = c->hy; ta.hz = c->hz; ta.hinfo = c->hinfo; ta.sunres = c->sunres; ta.counters = c->d_counters;
+
+        rtd::ShadeArgs sa{};
+        sa.qox = c->qox; sa.qoy = c->qoy; sa.qoz = c->qoz; sa.qdx = c->qdx; sa.qdy = c->qdy; sa.qdz = c->qdz; sa.qid = c->qid;
+        sa.qcap = c->cap; sa.npaths = npaths; sa.npaths_cap = c->cap; sa.npix_pad = c->npix_pad; sa.sample0 = s0;
+        sa.hx = c->hx; sa.hy = c->hy; sa.hz = c->hz; sa.hinfo = c->hinfo; sa.sunres = c->sunres;
+        sa.pdx = c->pdx; sa.pdy = c->pdy; sa.pdz = c->pdz; sa.pnormal = c->pnormal; sa.pstate = c->pstate;
+        sa.sunbits = c->sunbits; sa.stack = c->stack; sa.plx = c->plx; sa.ply = c->ply; sa.plz = c->plz;
+        sa.counters = c->d_counters;
+
+        // primary wave
+        ta.qcount = counts + 0; ta.cursor = cursors + 0;
+        { LaunchTimer t(c, 0); RT_HIP(c, rtd::launch_trace(sc, f, ta, true, count, c->num_cus, c->stream)); }
+        sa.qcount_next = counts + 1;
+        { LaunchTimer t(c, 1); RT_HIP(c, rtd::launch_shade0(sc, f, sa, pl, count, c->stream)); }
+        for (int level = 1; level <= D; level++) {
+            ta.qcount = counts + level; ta.cursor = cursors + level;
+            { LaunchTimer t(c, 0); RT_HIP(c, rtd::launch_trace(sc, f, ta, false, count, c->num_cus, c->stream)); }
+            sa.qcount_next = counts + level + 1;
+            { LaunchTimer t(c, 1); RT_HIP(c, rtd::launch_shadeN(sc, f, sa, level, count, c->stream)); }
+        }
+        { LaunchTimer t(c, 1); RT_HIP(c, rtd::launch_accumulate(c->plx, c->ply, c->plz, c->acc, c->npix_pad, ns, batch == 0, c->stream)); }
+    }
+    { LaunchTimer t(c, 1); RT_HIP(c, rtd::launch_resolve(f, c->acc, pl, c->npix_pad, c->stream)); }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return (1u << 16) | 0u; }
+
+const char* rt_last_error(RtContext* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_create(const RtConfig* cfg, RtContext** out) {
+    if (out) *out = nullptr;
+    if (!cfg || !out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: null argument");
+    if (cfg->struct_size != sizeof(RtConfig)) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: RtConfig.struct_size mismatch");
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 16384 || cfg->height > 16384)
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: width/height out of range");
+    if (cfg->region != RT_ROOT_BLOCK_SIZE) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: region must be 256");
+    if (cfg->spp < 1 || cfg->spp > RT_NOISE_BYTES) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: spp out of range");
+    if (cfg->depth < 0 || cfg->depth > RT_MAX_DEPTH) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: depth out of range");
+    if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world)
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: bad tile_rank/tile_world");
+    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_WAVEFRONT)
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown kernel");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, std::string("rt_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: device ordinal out of range");
+
+    RtContext* c = new (std::nothrow) RtContext();
+    if (!c) return fail(nullptr, RT_ERR_OOM, "rt_create: host allocation failed");
+    auto bail = [&](int code, const std::string& msg) { g_create_error = msg; rt_destroy(c); return code; };
+#define RT_HIP_CREATE(call)                                                                                        \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess)                                                             \
+        return bail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_WAVEFRONT : cfg->kernel;
+    RT_HIP_CREATE(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    RT_HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    RT_HIP_CREATE(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    RT_HIP_CREATE(hipEventCreate(&c->ev_frame0));
+    RT_HIP_CREATE(hipEventCreate(&c->ev_frame1));
+
+    // tiling: 8x8-pixel tiles dealt round-robin over tile_world contexts
+    c->tiles_x = (cfg->width + 7) / 8; c->tiles_y = (cfg->height + 7) / 8;
+    c->ntiles_total = c->tiles_x * c->tiles_y;
+    c->tile_capacity = (c->ntiles_total + cfg->tile_world - 1) / cfg->tile_world;
+    c->ntiles_local = (c->ntiles_total - cfg->tile_rank + cfg->tile_world - 1) / cfg->tile_world;
+    if (c->ntiles_local < 0) c->ntiles_local = 0;
+    c->npix_pad = (uint32_t)c->ntiles_local * 64u;
+    c->plane_pixels = cfg->tile_world == 1 ? (size_t)cfg->width * cfg->height : (size_t)c->tile_capacity * 64;
+
+    // scene
+    RT_HIP_CREATE(dev_alloc(c, &c->d_mine_lin, kVox)); RT_HIP_CREATE(dev_alloc(c, &c->d_mat_lin, kVox));
+    RT_HIP_CREATE(dev_alloc(c, &c->d_mine_sw, kVox)); RT_HIP_CREATE(dev_alloc(c, &c->d_mat_sw, kVox));
+    RT_HIP_CREATE(dev_alloc(c, &c->d_coarse, (size_t)rtd::kCoarseWords));
+    RT_HIP_CREATE(dev_alloc(c, &c->d_noise, (size_t)RT_NOISE_SIZE * RT_NOISE_SIZE));
+    RT_HIP_CREATE(dev_alloc(c, &c->d_flag, 4));
+    RT_HIP_CREATE(dev_alloc(c, &c->d_counters, 1));
+    RT_HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(rtd::DevCounters)));
+
+    for (int b = 0; b < RT_BUF_COUNT; b++) {
+        uint8_t* p = nullptr;
+        RT_HIP_CREATE(dev_alloc(c, &p, c->plane_pixels * kBytesPerPixel[b]));
+        RT_HIP_CREATE(hipMemset(p, 0, c->plane_pixels * kBytesPerPixel[b]));
+        c->planes[b] = p;
+    }
+
+    if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
+    if (c->kernel == RT_KERNEL_WAVEFRONT) {
+        uint64_t target = 4u << 20;   // paths per batch
+        if (const char* s = getenv("RT_BATCH_PATHS")) { long long v = atoll(s); if (v > 0) target = (uint64_t)v; }
+        uint64_t B = c->npix_pad ? target / c->npix_pad : 1;
+        if (B < 1) B = 1;
+        if (B > (uint64_t)cfg->spp) B = (uint64_t)cfg->spp;
+        c->batch_samples = (uint32_t)B;
+        uint64_t cap64 = (uint64_t)c->npix_pad * B;
+        if (cap64 >= (1ull << 31)) return bail(RT_ERR_INVALID_ARG, "rt_create: batch too large");
+        c->cap = (uint32_t)cap64;
+        const size_t cap = c->cap;
+        RT_HIP_CREATE(dev_alloc(c, &c->qox, cap)); RT_HIP_CREATE(dev_alloc(c, &c->qoy, cap)); RT_HIP_CREATE(dev_alloc(c, &c->qoz, cap));
+        RT_HIP_CREATE(dev_alloc(c, &c->qdx, 2 * cap)); RT_HIP_CREATE(dev_alloc(c, &c->qdy, 2 * cap)); RT_HIP_CREATE(dev_alloc(c, &c->qdz, 2 * cap));
+        RT_HIP_CREATE(dev_alloc(c, &c->qid, cap));
+        RT_HIP_CREATE(dev_alloc(c, &c->hx, cap)); RT_HIP_CREATE(dev_alloc(c, &c->hy, cap)); RT_HIP_CREATE(dev_alloc(c, &c->hz, cap));
+        RT_HIP_CREATE(dev_alloc(c, &c->hinfo, cap));
+        RT_HIP_CREATE(dev_alloc(c, &c->sunres, cap)); RT_HIP_CREATE(dev_alloc(c, &c->pnormal, cap)); RT_HIP_CREATE(dev_alloc(c, &c->pstate, cap));
+        RT_HIP_CREATE(dev_alloc(c, &c->pdx, cap)); RT_HIP_CREATE(dev_alloc(c, &c->pdy, cap)); RT_HIP_CREATE(dev_alloc(c, &c->pdz, cap));
+        RT_HIP_CREATE(dev_alloc(c, &c->plx, cap)); RT_HIP_CREATE(dev_alloc(c, &c->ply, cap)); RT_HIP_CREATE(dev_alloc(c, &c->plz, cap));
+        RT_HIP_CREATE(dev_alloc(c, &c->sunbits, cap));
+        RT_HIP_CREATE(dev_alloc(c, &c->stack, cap * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));
+        RT_HIP_CREATE(dev_alloc(c, &c->acc, (size_t)c->npix_pad));
+        RT_HIP_CREATE(dev_alloc(c, &c->ctrl, (size_t)2 * (RT_MAX_DEPTH + 2)));
+    }
+#undef RT_HIP_CREATE
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(RtContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->stream && ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->ev_frame0) (void)hipEventDestroy(ctx->ev_frame0);
+    if (ctx->ev_frame1) (void)hipEventDestroy(ctx->ev_frame1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int rt_set_stream(RtContext* ctx, void* hip_stream) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RT_OK;
+}
+
+int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* minefield) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!materials || !minefield) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_world: null pointer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(ctx->d_mat_lin, materials, kVox * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_mine_lin, minefield, kVox, hipMemcpyHostToDevice));
+    ctx->has_world = false;
+    int rc = reflatten(ctx);
+    if (rc != RT_OK) return rc;
+    ctx->has_world = true;
+    return RT_OK;
+}
+
+int rt_upload_slice(RtContext* ctx, int axis, int texel_offset, const uint32_t* materials, const uint8_t* minefield) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!materials || !minefield) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_slice: null pointer");
+    if (axis < 0 || axis > 2 || texel_offset < 0 || texel_offset + RT_SLICE_SIZE > kR || texel_offset % RT_SLICE_SIZE != 0)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_slice: bad axis or offset");
+    if (!ctx->has_world) return fail(ctx, RT_ERR_NOT_READY, "rt_upload_slice: upload the full region first");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t S = RT_SLICE_SIZE;
+    auto copy = [&](void* dst, const void* src, size_t elem) -> hipError_t {
+        char* d = (char*)dst;
+        if (axis == 2) return hipMemcpy(d + (size_t)texel_offset * kR * kR * elem, src, S * kR * kR * elem, hipMemcpyHostToDevice);
+        if (axis == 1)  // rows = z, each 16*R contiguous elements
+            return hipMemcpy2D(d + (size_t)texel_offset * kR * elem, (size_t)kR * kR * elem, src, S * kR * elem, S * kR * elem, kR,
+                               hipMemcpyHostToDevice);
+        // axis 0: rows = (z,y), each 16 contiguous elements
+        return hipMemcpy2D(d + (size_t)texel_offset * elem, (size_t)kR * elem, src, S * elem, S * elem, (size_t)kR * kR,
+                           hipMemcpyHostToDevice);
+    };
+    RT_HIP(ctx, copy(ctx->d_mat_lin, materials, sizeof(uint32_t)));
+    RT_HIP(ctx, copy(ctx->d_mine_lin, minefield, 1));
+    return reflatten(ctx);
+}
+
+int rt_upload_noise(RtContext* ctx, const uint8_t* rgba8) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!rgba8) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_noise: null pointer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(ctx->d_noise, rgba8, RT_NOISE_BYTES, hipMemcpyHostToDevice));
+    ctx->has_noise = true;
+    return RT_OK;
+}
+
+int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!u) return fail(ctx, RT_ERR_INVALID_ARG, "rt_draw_frame: null uniforms");
+    if (!ctx->has_world || !ctx->has_noise) return fail(ctx, RT_ERR_NOT_READY, "rt_draw_frame: world and noise must be uploaded first");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const rtd::Frame f = frame_of(ctx, u);
+    const bool count = (ctx->cfg.flags & RT_FLAG_COUNTERS) != 0;
+    if (ctx->cfg.flags & RT_FLAG_TIMING) {
+        // the previous frame's events are about to be reused
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->ev_used = 0;
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
+    int rc = RT_OK;
+    if (ctx->kernel == RT_KERNEL_MEGA) {
+        LaunchTimer t(ctx, 0);
+        hipError_t e = rtd::launch_mega(scene_of(ctx), f, planes_of(ctx), ctx->d_counters, count, ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("launch_mega: ") + hipGetErrorString(e));
+    } else {
+        rc = draw_wavefront(ctx, f);
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+    ctx->frame_recorded = true;
+    if (count) { ctx->host_noise_base += (uint64_t)ctx->cfg.spp; ctx->host_frames++; }
+    return rc;
+}
+
+int rt_sync(RtContext* ctx) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+size_t rt_buffer_bytes(RtContext* ctx, int id) {
+    if (!ctx || id < 0 || id >= RT_BUF_COUNT) return 0;
+    return ctx->plane_pixels * kBytesPerPixel[id];
+}
+
+void* rt_device_ptr(RtContext* ctx, int id) {
+    if (!ctx || id < 0 || id >= RT_BUF_COUNT) return nullptr;
+    return ctx->planes[id];
+}
+
+int rt_readback(RtContext* ctx, int id, void* dst, size_t bytes) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (id < 0 || id >= RT_BUF_COUNT || !dst) return fail(ctx, RT_ERR_INVALID_ARG, "rt_readback: bad buffer id or null destination");
+    if (bytes != rt_buffer_bytes(ctx, id)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_readback: size mismatch");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(dst, ctx->planes[id], bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_tile_count(RtContext* ctx) { return ctx ? ctx->ntiles_local : RT_ERR_INVALID_ARG; }
+int rt_tile_capacity(RtContext* ctx) { return ctx ? ctx->tile_capacity : RT_ERR_INVALID_ARG; }
+
+int rt_untile(RtContext* ctx, int id, const void* gathered_dev, int world, void* frame_dev) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (id < 0 || id >= RT_BUF_COUNT || !gathered_dev || !frame_dev || world < 1)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_untile: bad argument");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int capacity = (ctx->ntiles_total + world - 1) / world;
+    RT_HIP(ctx, rtd::launch_untile(gathered_dev, frame_dev, world, capacity, ctx->tiles_x, ctx->tiles_y, ctx->cfg.width,
+                                   ctx->cfg.height, (int)kBytesPerPixel[id], ctx->stream));
+    return RT_OK;
+}
+
+int rt_get_counters(RtContext* ctx, RtCounters* out) {
+    if (!ctx || !out) return RT_ERR_INVALID_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rtd::DevCounters d;
+    RT_HIP(ctx, hipMemcpy(&d, ctx->d_counters, sizeof(d), hipMemcpyDeviceToHost));
+    out->rays = d.rays; out->rays_primary = d.rays_primary; out->rays_shadow = d.rays_shadow; out->rays_diffuse = d.rays_diffuse;
+    out->iterations = d.iterations; out->minefield_fetches = d.minefield_fetches; out->material_fetches = d.material_fetches;
+    out->noise_fetches = d.noise_fetches + ctx->host_noise_base;   // + the seed-base texel of each sample (raytrace.comp:302-303)
+    out->hits = d.hits; out->sky_exits = d.sky_exits; out->limit_exits = d.limit_exits; out->border_fetches = d.border_fetches;
+    out->pixels = d.pixels; out->frames = ctx->host_frames;
+    return RT_OK;
+}
+
+int rt_reset_counters(RtContext* ctx) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemset(ctx->d_counters, 0, sizeof(rtd::DevCounters)));
+    ctx->host_noise_base = 0; ctx->host_frames = 0;
+    return RT_OK;
+}
+
+int rt_get_timing(RtContext* ctx, RtTiming* out) {
+    if (!ctx || !out) return RT_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_get_timing: no frame drawn yet");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipEventElapsedTime(&out->frame_ms, ctx->ev_frame0, ctx->ev_frame1));
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.0f;
+        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+        if (ctx->ev_kind[i / 2] == 0) { out->trace_ms += ms; out->trace_launches++; }
+        else { out->shade_ms += ms; out->other_launches++; }
+    }
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// rt_kernels.hpp — argument blocks and host-callable launchers of the kernels in rt_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.hpp"
+
+namespace rtd {
+
+// SoA ray queue + per-path hit/state arrays, all in HBM (sizes in elements; cap = paths per batch).
+//   queue : origin qo*[cap] shared by the pair, directions qd*[2*cap] (shadow at slot, diffuse at cap+slot), qid[cap] = path
+//   hits  : hx,hy,hz,hinfo[cap] (diffuse / primary result per path), sunres[cap] (shadow ray reached the sky)
+struct TraceArgs {
+    const float *qox, *qoy, *qoz, *qdx, *qdy, *qdz;
+    const uint32_t* qid;
+    const uint32_t* qcount;     // number of queued pairs (written by the previous shade stage)
+    uint32_t* cursor;           // global ray cursor, zero before launch
+    uint32_t qcap;
+    uint32_t nprimary;          // MODE 0: number of paths in the batch
+    uint32_t npix_pad;          // MODE 0: paths per sample (local pixels padded to whole tiles)
+    uint32_t refill_threshold;  // idle lanes per wave that trigger retire + refill (1..64)
+    float *hx, *hy, *hz;
+    uint32_t* hinfo;            // material[20:0] | face id << 24 | limit << 30 | air << 31
+    uint8_t* sunres;
+    DevCounters* counters;
+};
+
+struct ShadeArgs {
+    float *qox, *qoy, *qoz, *qdx, *qdy, *qdz;
+    uint32_t* qid;
+    uint32_t* qcount_next;      // pairs appended by this stage (zero before launch)
+    uint32_t qcap;
+    uint32_t npaths;            // paths in this batch
+    uint32_t npaths_cap;        // allocation stride of the per-level albedo stack
+    uint32_t npix_pad;
+    uint32_t sample0;           // index of the batch's first sample within the frame
+    const float *hx, *hy, *hz;
+    const uint32_t* hinfo;
+    const uint8_t* sunres;
+    float *pdx, *pdy, *pdz;     // diffuse direction of the level in flight (sample_sky argument on a sky exit)
+    uint8_t* pnormal;
+    uint8_t* pstate;            // 1 = path still has rays in flight
+    uint32_t* sunbits;          // bit j-1: shadow ray of level j reached the sky
+    uint32_t* stack;            // [(depth-1)][npaths_cap] packed material of surface j+1
+    float *plx, *ply, *plz;     // finished light of the path
+    DevCounters* counters;
+};
+
+hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
+                          uint32_t* coarse, uint32_t* bad_flag, hipStream_t st);
+hipError_t launch_mega(const Scene& sc, const Frame& f, const Planes& pl, DevCounters* cn, bool count, hipStream_t st);
+hipError_t launch_trace(const Scene& sc, const Frame& f, const TraceArgs& a, bool primary, bool count, int nworkgroups, hipStream_t st);
+hipError_t launch_shade0(const Scene& sc, const Frame& f, const ShadeArgs& a, const Planes& pl, bool count, hipStream_t st);
+hipError_t launch_shadeN(const Scene& sc, const Frame& f, const ShadeArgs& a, int level, bool count, hipStream_t st);
+hipError_t launch_accumulate(const float* plx, const float* ply, const float* plz, float4* acc, uint32_t npix_pad,
+                             uint32_t nsamples, bool first_batch, hipStream_t st);
+hipError_t launch_resolve(const Frame& f, const float4* acc, const Planes& pl, uint32_t npix_pad, hipStream_t st);
+hipError_t launch_untile(const void* gathered, void* frame, int world, int capacity, int tiles_x, int tiles_y, int width,
+                         int height, int bpp, hipStream_t st);
+
+}  // namespace rtd
