@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the ray-trace path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one frame of the workload BASELINE.json's metric is quoted on: 1920x1080, spp=64, depth=4, the procedural
+256^3 region (seed 0x5EED), the reference's default pose.  Inputs are resident in HBM before the timed region.
+With N > 1 the frame's 8x8 tiles are dealt round-robin over the ranks (no collective while rendering) and the six
+G-buffer planes are gathered to rank 0 over RCCL and un-tiled at frame end, inside the timed step.
+
+Prints ONE JSON line on rank 0 (metric/value/... + "roofline" + "cpu_baseline").
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+class _DevArray:
+    """Zero-copy view of a device pointer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--kernel", choices=["persistent", "wavefront", "mega"], default="persistent")
+    ap.add_argument("--cache-primary", action="store_true", help="trace the seed-independent primary ray once per pixel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(mats, mine, noise, u, width, height, depth, rows_hint):
+    """The CPU oracle (a port: the reference has no CPU renderer) timed on the host cores on a bounded sample:
+    one of the spp samples over a band of rows centred on the horizon, sized for roughly 10-20 s."""
+    from oracle import pyoracle as po
+    cores = os.cpu_count() or 1
+    # calibrate on 16 rows, then size the band
+    y_mid = height // 2
+    t0 = time.perf_counter()
+    _, cn = po.render(mats, mine, noise, u, width, height, 1, depth, rows=(y_mid - 8, y_mid + 8))
+    dt = max(time.perf_counter() - t0, 1e-3)
+    rows = rows_hint if rows_hint > 0 else int(min(height, max(32, 16 * 12.0 / dt)))
+    rows -= rows % 2
+    y0 = max(0, y_mid - rows // 2)
+    y1 = min(height, y0 + rows)
+    t0 = time.perf_counter()
+    _, cn = po.render(mats, mine, noise, u, width, height, 1, depth, rows=(y0, y1))
+    dt = time.perf_counter() - t0
+    return {"value": round(cn.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "oracle (scalar fp32 C++, OpenMP dynamic over rows), %dx%d rows [%d,%d) of 1 sample (seed %d), depth %d: "
+                      "%d rays in %.2f s" % (width, height, y0, y1, u.seed, depth, cn.rays, dt)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from raytrace_amd import abi, build, render, world as rt_world
+
+    if rank == 0:
+        build.build()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    W, H, SPP, D = args.width, args.height, args.spp, args.depth
+    kernel = {"persistent": abi.RT_KERNEL_PERSISTENT, "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
+    xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
+    noise = np.fromfile(os.path.join(ROOT, "tests", "golden", "blue_noise_512.rgba"), dtype=np.uint8)
+    mats, mine = rt_world.generate_region(rt_world.DEFAULT_SEED)
+    pose = render.DEFAULT_POSE
+    u = render.camera_uniforms(pose["origin"], pose["heading"], pose["pitch"], pose["sun_angle"], seed=1)
+
+    def make_ctx(flags):
+        cfg = render.make_config(W, H, spp=SPP, depth=D, device=local_rank, tile_rank=rank, tile_world=world,
+                                 kernel=kernel, flags=flags | xflags)
+        ctx = render.Context(cfg)
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(noise)
+        return ctx
+
+    # ---- exact ray / byte counts of one frame (deterministic; outside the timed region) --------------------
+    cctx = make_ctx(abi.RT_FLAG_COUNTERS)
+    cctx.draw_frame(u)
+    cctx.sync()
+    cn = cctx.counters()
+    cctx.destroy()
+    rays_local = cn.rays
+    # traversal-kernel algorithmic bytes: 1 B per minefield fetch + 4 B per material fetch
+    trace_bytes_local = cn.minefield_fetches + 4 * cn.material_fetches
+    balg_local = cn.algorithmic_bytes()
+
+    ctx = make_ctx(abi.RT_FLAG_TIMING)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    gather_ids = [abi.RT_BUF_LIGHTING_RGBA16, abi.RT_BUF_DEPTH_R16UI, abi.RT_BUF_NORMAL_R8UI, abi.RT_BUF_ALBEDO_RGBA8,
+                  abi.RT_BUF_EMISSION_RGBA8, abi.RT_BUF_FOG_RGBA8]
+    bpp = {abi.RT_BUF_LIGHTING_RGBA16: 8, abi.RT_BUF_DEPTH_R16UI: 2, abi.RT_BUF_NORMAL_R8UI: 1, abi.RT_BUF_ALBEDO_RGBA8: 4,
+           abi.RT_BUF_EMISSION_RGBA8: 4, abi.RT_BUF_FOG_RGBA8: 4}
+    if world > 1:
+        local_views = {b: torch.as_tensor(_DevArray(ctx.device_ptr(b), ctx.buffer_bytes(b)), device=dev) for b in gather_ids}
+        gathered = {b: torch.empty(world * ctx.buffer_bytes(b), dtype=torch.uint8, device=dev) if rank == 0 else None
+                    for b in gather_ids}
+        frames = {b: torch.empty(W * H * bpp[b], dtype=torch.uint8, device=dev) if rank == 0 else None for b in gather_ids}
+
+    def step():
+        ctx.draw_frame(u)
+        if world > 1:
+            for b in gather_ids:
+                if rank == 0:
+                    dist.gather(local_views[b], list(gathered[b].chunk(world)), dst=0)
+                    ctx.untile(b, gathered[b].data_ptr(), world, frames[b].data_ptr())
+                else:
+                    dist.gather(local_views[b], None, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    trace_ms = 0.0
+    trace_launches = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # per-launch HIP events of this frame (recorded on the stream the kernels run on)
+        tm = ctx.timing()
+        trace_ms += tm.trace_ms
+        trace_launches += tm.trace_launches
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    sums = torch.tensor([float(rays_local), float(trace_bytes_local), float(balg_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    elapsed = float(t_all.item())
+    rays_total, trace_bytes_total, balg_total = [float(x) for x in sums.tolist()]
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mrays = rays_total * args.steps / elapsed / 1e6
+        # roofline of the dominant kernel (k_trace) on this rank: algorithmic bytes of its launches / their duration
+        achieved = (trace_bytes_local * args.steps) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r1.json")
+        if os.path.exists(tpath) and (W, H, SPP, D) == (1920, 1080, 64, 4) and world == 1:
+            try:
+                traffic = json.load(open(tpath)).get("k_trace_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s at 1920x1080 spp=64 (rays actually traced: primary + shadow + diffuse)",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d spp=%d depth=%d, procedural 256^3 region seed 0x5EED, pose (-30,-128,100) h=pi/2 p=0 sun=0"
+                                   % (W, H, SPP, D), "kernel": args.kernel, "rays_per_frame": int(rays_total),
+                       "algorithmic_bytes_per_frame": int(balg_total), "parallelism": "tiles%d" % world,
+                       "primary_cache": bool(args.cache_primary)},
+            "roofline": {"bound": "hbm", "kernel": {"persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}[args.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "launches_per_frame": trace_launches // max(args.steps, 1),
+                         "avg_launch_ms": round(trace_ms / max(trace_launches, 1), 4),
+                         "algorithmic_bytes_per_launch": int(trace_bytes_local / max(trace_launches // max(args.steps, 1), 1))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mats, mine, noise, u, W, H, D, args.cpu_rows)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    ctx.destroy()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

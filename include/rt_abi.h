@@ -91,9 +91,11 @@ typedef struct RtUniforms {
 
 /* Which traversal implementation a context uses. */
 typedef enum RtKernel {
-    RT_KERNEL_DEFAULT = 0,   /* library picks (wavefront)                                           */
-    RT_KERNEL_MEGA = 1,      /* one thread per pixel, all rays inline, byte minefield from HBM      */
-    RT_KERNEL_WAVEFRONT = 2  /* persistent wave64 traversal, ballot refill, LDS brick map, SoA rays */
+    RT_KERNEL_DEFAULT = 0,    /* library picks (persistent)                                                    */
+    RT_KERNEL_MEGA = 1,       /* one thread per pixel, all rays inline, byte minefield from HBM (baseline)      */
+    RT_KERNEL_WAVEFRONT = 2,  /* split stages: persistent traversal kernel fed by SoA ray/hit queues in HBM     */
+    RT_KERNEL_PERSISTENT = 3  /* persistent wave64 path kernel: lane owns a pixel, state in registers, __ballot
+                                 batched transitions, nibble map in LDS (production kernel)                     */
 } RtKernel;
 
 #define RT_FLAG_COUNTERS      0x1u  /* count rays/iterations/hits exactly (slower; for B_alg + parity)   */

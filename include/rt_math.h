@@ -5,15 +5,18 @@
  * 1-ulp difference in a ray direction flips which voxel a grazing ray enters (an O(1) pixel
  * error).  "Same result as the reference on the same inputs" is therefore only well-defined
  * once the elementary functions are pinned.  This header pins them: every function below is
- * built from IEEE-754 binary32 +, -, *, /, sqrt, floor and integer bit operations only — all
- * of which are correctly rounded both on x86-64 (SSE) and on gfx950 — so any conforming
- * compilation (g++ or hipcc, with FP contraction OFF: -ffp-contract=off) yields the same bits.
+ * built from IEEE-754 binary32 +, -, *, /, sqrt, floor, EXPLICIT fused multiply-add (rtm_fma)
+ * and integer bit operations only — all of which are correctly rounded both on x86-64 (SSE/FMA3)
+ * and on gfx950 — so any conforming compilation (g++ -mfma or hipcc, with IMPLICIT contraction
+ * OFF: -ffp-contract=off) yields the same bits.  (GLSL permits a*b+c to be fused unless marked
+ * `precise`; where this contract fuses, it says so explicitly.)
  *
  * It is part of the ABI (like rt_abi.h), not of the oracle: the CPU oracle under oracle/
  * restates the shader's ALGORITHM independently and only shares these definitions of the
  * elementary operations.  tests/test_math_contract.py checks each function against libm.
  *
- * Rules for users: compile with -ffp-contract=off; do not use -ffast-math; on hipcc keep the
+ * Rules for users: compile with -ffp-contract=off (and -mfma on x86 so rtm_fma is one instruction;
+ * without it libm's fmaf gives the same result, slowly); do not use -ffast-math; on hipcc keep the
  * default -fhip-fp32-correctly-rounded-divide-sqrt and do not flush denormals.
  *
  * Polynomial coefficients are the classic single-precision minimax sets (Cephes sinf/cosf/
@@ -39,20 +42,22 @@ RTM_HD uint32_t rtm_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 RTM_HD float rtm_from_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
 
 RTM_HD float rtm_floor(float x) { return __builtin_floorf(x); }
+/* fused multiply-add, one rounding: a*b + c */
+RTM_HD float rtm_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 RTM_HD float rtm_sqrt(float x) { return __builtin_sqrtf(x); }
 RTM_HD float rtm_abs(float x) { return __builtin_fabsf(x); }
 /* GLSL min/max: min(x,y) = y < x ? y : x ; max(x,y) = x < y ? y : x */
 RTM_HD float rtm_min(float x, float y) { return y < x ? y : x; }
 RTM_HD float rtm_max(float x, float y) { return x < y ? y : x; }
 RTM_HD float rtm_clamp(float x, float lo, float hi) { return rtm_min(rtm_max(x, lo), hi); }
-/* GLSL mix(x,y,a) = x*(1-a) + y*a */
-RTM_HD float rtm_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+/* GLSL mix(x,y,a) = x*(1-a) + y*a (second product fused into the sum) */
+RTM_HD float rtm_mix(float x, float y, float a) { return rtm_fma(y, a, x * (1.0f - a)); }
 /* GLSL mod(x,y) = x - y*floor(x/y) */
 RTM_HD float rtm_mod(float x, float y) { return x - y * rtm_floor(x / y); }
 
-RTM_HD float rtm_dot3(rtm_vec3 a, rtm_vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-RTM_HD float rtm_length3(rtm_vec3 v) { return rtm_sqrt((v.x * v.x + v.y * v.y) + v.z * v.z); }
-RTM_HD float rtm_length2(float x, float y) { return rtm_sqrt(x * x + y * y); }
+RTM_HD float rtm_dot3(rtm_vec3 a, rtm_vec3 b) { return rtm_fma(a.z, b.z, rtm_fma(a.y, b.y, a.x * b.x)); }
+RTM_HD float rtm_length3(rtm_vec3 v) { return rtm_sqrt(rtm_fma(v.z, v.z, rtm_fma(v.y, v.y, v.x * v.x))); }
+RTM_HD float rtm_length2(float x, float y) { return rtm_sqrt(rtm_fma(y, y, x * x)); }
 /* normalize(v) = v * (1/length(v)) */
 RTM_HD rtm_vec3 rtm_normalize3(rtm_vec3 v) {
     float r = 1.0f / rtm_length3(v);
@@ -65,14 +70,14 @@ RTM_HD rtm_vec3 rtm_normalize3(rtm_vec3 v) {
  * range the result is defined as sin = 0, cos = 1. */
 RTM_HD void rtm_sincos(float x, float* s_out, float* c_out) {
     if (!(rtm_abs(x) < 1.0e5f)) { *s_out = 0.0f; *c_out = 1.0f; return; }
-    float k = rtm_floor(x * 0.63661977236758134308f + 0.5f);
-    /* three-part pi/2 (Cody-Waite); the products with small k are exact or nearly so */
-    float r = ((x - k * 1.5703125f) - k * 4.837512969970703125e-4f) - k * 7.54978995489188216e-8f;
+    float k = rtm_floor(rtm_fma(x, 0.63661977236758134308f, 0.5f));
+    /* three-part pi/2 (Cody-Waite) */
+    float r = rtm_fma(-k, 7.54978995489188216e-8f, rtm_fma(-k, 4.837512969970703125e-4f, rtm_fma(-k, 1.5703125f, x)));
     int q = ((int)k) & 3;
     float z = r * r;
-    float s = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    float c = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
-              - 0.5f * z + 1.0f;
+    float s = rtm_fma(rtm_fma(rtm_fma(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    float c = rtm_fma(rtm_fma(rtm_fma(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                      rtm_fma(-0.5f, z, 1.0f));
     float ss, cc;
     if (q == 0)      { ss = s;  cc = c;  }
     else if (q == 1) { ss = c;  cc = -s; }
@@ -87,12 +92,13 @@ RTM_HD float rtm_cos(float x) { float s, c; rtm_sincos(x, &s, &c); return c; }
 /* ---- acos ------------------------------------------------------------------------------ */
 RTM_HD float rtm_asin_poly(float a) { /* |a| <= 0.5 */
     float z = a * a;
-    return a + a * z * ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z
-                         + 7.4953002686e-2f) * z + 1.6666752422e-1f);
+    float p = rtm_fma(rtm_fma(rtm_fma(rtm_fma(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z,
+                              7.4953002686e-2f), z, 1.6666752422e-1f);
+    return rtm_fma(a * z, p, a);
 }
 RTM_HD float rtm_acos(float x) {
     x = rtm_clamp(x, -1.0f, 1.0f);
-    if (x < -0.5f) return RTM_PI - 2.0f * rtm_asin_poly(rtm_sqrt(0.5f * (1.0f + x)));
+    if (x < -0.5f) return rtm_fma(-2.0f, rtm_asin_poly(rtm_sqrt(0.5f * (1.0f + x))), RTM_PI);
     if (x > 0.5f)  return 2.0f * rtm_asin_poly(rtm_sqrt(0.5f * (1.0f - x)));
     return RTM_PIO2 - rtm_asin_poly(x);
 }
@@ -106,11 +112,16 @@ RTM_HD float rtm_log2_pos(float x) {
     if (m < 0.70710678118654752440f) { e -= 1; m = (m + m) - 1.0f; }
     else { m = m - 1.0f; }
     float z = m * m;
-    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m
-                    - 1.2420140846e-1f) * m + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m
-                 + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m + 3.3333331174e-1f) * m * z;
-    y = y - 0.5f * z;
-    return (m + y) * 1.44269504088896340736f + (float)e;
+    float y = rtm_fma(7.0376836292e-2f, m, -1.1514610310e-1f);
+    y = rtm_fma(y, m, 1.1676998740e-1f);
+    y = rtm_fma(y, m, -1.2420140846e-1f);
+    y = rtm_fma(y, m, 1.4249322787e-1f);
+    y = rtm_fma(y, m, -1.6668057665e-1f);
+    y = rtm_fma(y, m, 2.0000714765e-1f);
+    y = rtm_fma(y, m, -2.4999993993e-1f);
+    y = rtm_fma(y, m, 3.3333331174e-1f);
+    y = rtm_fma(y * m, z, -0.5f * z);
+    return rtm_fma(m + y, 1.44269504088896340736f, (float)e);
 }
 RTM_HD float rtm_exp2(float x) {
     if (!(x > -126.0f)) return 0.0f;      /* underflow (and NaN) -> 0 */
@@ -118,9 +129,12 @@ RTM_HD float rtm_exp2(float x) {
     float i = rtm_floor(x);
     float f = x - i;
     if (f > 0.5f) { i += 1.0f; f -= 1.0f; }
-    float p = (((((1.535336188319500e-4f * f + 1.339887440266574e-3f) * f + 9.618437357674640e-3f) * f
-                 + 5.550332471162809e-2f) * f + 2.402264791363012e-1f) * f + 6.931472028550421e-1f) * f
-              + 1.0f;
+    float p = rtm_fma(1.535336188319500e-4f, f, 1.339887440266574e-3f);
+    p = rtm_fma(p, f, 9.618437357674640e-3f);
+    p = rtm_fma(p, f, 5.550332471162809e-2f);
+    p = rtm_fma(p, f, 2.402264791363012e-1f);
+    p = rtm_fma(p, f, 6.931472028550421e-1f);
+    p = rtm_fma(p, f, 1.0f);
     int ii = (int)i;
     if (ii < -126) return 0.0f;
     if (ii > 127) ii = 127;

@@ -85,12 +85,19 @@ inline int border_texel(float c) {
     return (int)c;  // floor for c >= 0
 }
 
+// Optional fetch statistics for kernel design studies (single-threaded use): per fetched value, how many fetches
+// landed in a 4^3 brick whose 64 values are all equal.
+static const uint8_t* g_uniform4 = nullptr;   // [64^3] 1 = uniform brick
+static uint64_t g_fetch_hist[2][32];
+
 // get_step — raytrace.comp:78-80.  Border colour INT_OPAQUE_BLACK => 0 (render_data.rs:97-98).
 inline uint32_t get_step(const Scene& sc, vec3 tex_pos, Counters& cn) {
     cn.minefield_fetches++;
     int ix = border_texel(tex_pos.x), iy = border_texel(tex_pos.y), iz = border_texel(tex_pos.z);
     if ((ix | iy | iz) < 0) { cn.border_fetches++; return 0; }
-    return sc.minefield[((size_t)iz * R + iy) * R + ix];
+    const uint8_t v = sc.minefield[((size_t)iz * R + iy) * R + ix];
+    if (g_uniform4) g_fetch_hist[g_uniform4[((size_t)(iz >> 2) * 64 + (iy >> 2)) * 64 + (ix >> 2)] ? 1 : 0][v & 31]++;
+    return v;
 }
 
 // textureLod(world, mod((pos+off)/256, 1.0), 0).r — raytrace.comp:150-154; sampler render_data.rs:62-73
@@ -139,12 +146,17 @@ HitResult trace_ray(const Scene& sc, const int32_t lr[3], vec3 origin, vec3 dire
         vec3 l = {(0.0001f + rtm_mod(q.x, ss)) * length_per_axis.x,
                   (0.0001f + rtm_mod(q.y, ss)) * length_per_axis.y,
                   (0.0001f + rtm_mod(q.z, ss)) * length_per_axis.z};          // :119
+        // result.position += direction * length: the multiply-add is fused (rt_math.h contract; GLSL allows it)
+        auto advance = [&](float t) {
+            result.position = {rtm_fma(direction.x, t, result.position.x), rtm_fma(direction.y, t, result.position.y),
+                               rtm_fma(direction.z, t, result.position.z)};
+        };
         if (l.x < l.y) {                                                      // :120-136
-            if (l.x < l.z) { result.position = result.position + direction * l.x; result.normal = normals[0]; }
-            else           { result.position = result.position + direction * l.z; result.normal = normals[2]; }
+            if (l.x < l.z) { advance(l.x); result.normal = normals[0]; }
+            else           { advance(l.z); result.normal = normals[2]; }
         } else {
-            if (l.y < l.z) { result.position = result.position + direction * l.y; result.normal = normals[1]; }
-            else           { result.position = result.position + direction * l.z; result.normal = normals[2]; }
+            if (l.y < l.z) { advance(l.y); result.normal = normals[1]; }
+            else           { advance(l.z); result.normal = normals[2]; }
         }
         current_step = get_step(sc, texpos(result.position), cn);            // :137
         if (rtm_abs(result.position.x - current_rotation.x) >= W / 2 ||
@@ -427,6 +439,9 @@ int rt_oracle_render(const uint32_t* materials, const uint8_t* minefield, const 
     }
     return RT_OK;
 }
+
+void rt_oracle_fetch_stats_begin(const uint8_t* uniform4) { g_uniform4 = uniform4; memset(g_fetch_hist, 0, sizeof(g_fetch_hist)); }
+void rt_oracle_fetch_stats_end(uint64_t* out64) { memcpy(out64, g_fetch_hist, sizeof(g_fetch_hist)); g_uniform4 = nullptr; }
 
 // ---- single-function entry points for the known-answer tests ---------------------------------
 struct RtOracleHit {

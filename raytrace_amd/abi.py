@@ -19,9 +19,10 @@ RT_ERR_NOT_READY = -4
 RT_ERR_UNIMPLEMENTED = -5
 RT_ERR_OOM = -6
 
-RT_KERNEL_DEFAULT, RT_KERNEL_MEGA, RT_KERNEL_WAVEFRONT = 0, 1, 2
+RT_KERNEL_DEFAULT, RT_KERNEL_MEGA, RT_KERNEL_WAVEFRONT, RT_KERNEL_PERSISTENT = 0, 1, 2, 3
 RT_FLAG_COUNTERS = 0x1
 RT_FLAG_CACHE_PRIMARY = 0x2
+RT_FLAG_TIMING = 0x4
 
 (RT_BUF_LIGHTING_RGBA16, RT_BUF_DEPTH_R16UI, RT_BUF_NORMAL_R8UI, RT_BUF_ALBEDO_RGBA8,
  RT_BUF_EMISSION_RGBA8, RT_BUF_FOG_RGBA8, RT_BUF_LIGHTING_F32, RT_BUF_FOG_F32,

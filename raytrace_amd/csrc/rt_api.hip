@@ -47,7 +47,7 @@ struct RtContext {
     void* planes[RT_BUF_COUNT] = {};
 
     // wavefront pipeline state
-    int kernel = RT_KERNEL_WAVEFRONT;
+    int kernel = RT_KERNEL_PERSISTENT;
     uint32_t batch_samples = 1;   // samples per batch
     uint32_t cap = 0;             // paths per batch (allocation)
     uint32_t refill_threshold = 24;
@@ -60,6 +60,19 @@ struct RtContext {
     uint32_t *sunbits = nullptr, *stack = nullptr;
     float4* acc = nullptr;
     uint32_t* ctrl = nullptr;     // per batch: [RT_MAX_DEPTH+2] pair counts, then [RT_MAX_DEPTH+2] cursors
+    // persistent kernel state
+    uint32_t* pcursor = nullptr;   // [0] work cursor, [1] worklist count
+    uint32_t* pstack = nullptr;
+    uint32_t* worklist = nullptr;
+    float *phx = nullptr, *phy = nullptr, *phz = nullptr;
+    uint32_t* pinfo = nullptr;
+    float4* sphere_lut = nullptr;
+    float4* sun_lut = nullptr;
+    float4* dif_lut = nullptr;
+    float4* pacc = nullptr;
+    float *pplx = nullptr, *pply = nullptr, *pplz = nullptr;
+    uint32_t persist_batch = 1;
+    uint32_t persist_threshold = 32, persist_threshold_sun = 16;
     rtd::DevCounters* d_counters = nullptr;
     uint64_t host_noise_base = 0, host_frames = 0;
 
@@ -242,7 +255,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (cfg->depth < 0 || cfg->depth > RT_MAX_DEPTH) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: depth out of range");
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: bad tile_rank/tile_world");
-    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_WAVEFRONT)
+    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_PERSISTENT)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown kernel");
 
     int ndev = 0;
@@ -260,7 +273,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
 
     c->cfg = *cfg;
     c->device = cfg->device;
-    c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_WAVEFRONT : cfg->kernel;
+    c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PERSISTENT : cfg->kernel;
     RT_HIP_CREATE(hipSetDevice(c->device));
     hipDeviceProp_t prop;
     RT_HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
@@ -296,6 +309,33 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     }
 
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
+    if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
+    if (const char* s = getenv("RT_PERSIST_THRESHOLD_SUN")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold_sun = (uint32_t)v; }
+    if (c->kernel == RT_KERNEL_PERSISTENT) {
+        RT_HIP_CREATE(dev_alloc(c, &c->pcursor, 2));
+        RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));
+        RT_HIP_CREATE(dev_alloc(c, &c->worklist, (size_t)c->npix_pad));
+        RT_HIP_CREATE(dev_alloc(c, &c->phx, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->phy, (size_t)c->npix_pad));
+        RT_HIP_CREATE(dev_alloc(c, &c->phz, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->pinfo, (size_t)c->npix_pad));
+        RT_HIP_CREATE(dev_alloc(c, &c->sphere_lut, (size_t)65536));
+        RT_HIP_CREATE(dev_alloc(c, &c->sun_lut, (size_t)2 * 65536));
+        RT_HIP_CREATE(dev_alloc(c, &c->dif_lut, (size_t)3 * 6 * 65536));
+        RT_HIP_CREATE(dev_alloc(c, &c->pacc, (size_t)c->npix_pad));
+        {   // samples per k_persist launch: bounded by 2 GiB of per-path light and by 2^30 work items
+            uint64_t np = c->npix_pad ? c->npix_pad : 1;
+            uint64_t B = (2ull << 30) / (12ull * np);
+            if (B > (1ull << 30) / np) B = (1ull << 30) / np;
+            if (const char* s = getenv("RT_PERSIST_BATCH")) { long long v = atoll(s); if (v > 0) B = (uint64_t)v; }
+            if (B < 1) B = 1;
+            if (B > (uint64_t)cfg->spp) B = (uint64_t)cfg->spp;
+            c->persist_batch = (uint32_t)B;
+            size_t n = (size_t)np * B;
+            RT_HIP_CREATE(dev_alloc(c, &c->pplx, n)); RT_HIP_CREATE(dev_alloc(c, &c->pply, n)); RT_HIP_CREATE(dev_alloc(c, &c->pplz, n));
+        }
+        RT_HIP_CREATE(rtd::launch_sphere_lut(c->sphere_lut, c->own_stream));
+        RT_HIP_CREATE(rtd::launch_dif_lut(c->sphere_lut, c->dif_lut, c->own_stream));
+        RT_HIP_CREATE(hipStreamSynchronize(c->own_stream));
+    }
     if (c->kernel == RT_KERNEL_WAVEFRONT) {
         uint64_t target = 4u << 20;   // paths per batch
         if (const char* s = getenv("RT_BATCH_PATHS")) { long long v = atoll(s); if (v > 0) target = (uint64_t)v; }
@@ -412,6 +452,48 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         LaunchTimer t(ctx, 0);
         hipError_t e = rtd::launch_mega(scene_of(ctx), f, planes_of(ctx), ctx->d_counters, count, ctx->stream);
         if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("launch_mega: ") + hipGetErrorString(e));
+    } else if (ctx->kernel == RT_KERNEL_PERSISTENT) {
+        const bool cache = (ctx->cfg.flags & RT_FLAG_CACHE_PRIMARY) != 0;
+        hipError_t e = hipMemsetAsync(ctx->pcursor, 0, 2 * sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess && cache) {
+            LaunchTimer t(ctx, 1);
+            rtd::PrimaryArgs pr{};
+            pr.phx = ctx->phx; pr.phy = ctx->phy; pr.phz = ctx->phz; pr.pinfo = ctx->pinfo;
+            pr.worklist = ctx->worklist; pr.wl_count = ctx->pcursor + 1; pr.acc = ctx->pacc; pr.counters = ctx->d_counters;
+            e = rtd::launch_primary(scene_of(ctx), f, planes_of(ctx), pr, count, ctx->stream);
+        }
+        if (e == hipSuccess && ctx->cfg.depth >= 1) {
+            LaunchTimer t(ctx, 1);
+            e = rtd::launch_sun_lut(f, ctx->sun_lut, ctx->stream);
+        }
+        if (!cache || ctx->cfg.depth >= 1) {
+            const uint32_t spp = (uint32_t)ctx->cfg.spp, B = ctx->persist_batch;
+            for (uint32_t s0 = 0; s0 < spp && e == hipSuccess; s0 += B) {
+                const uint32_t ns = spp - s0 < B ? spp - s0 : B;
+                if (s0 != 0) e = hipMemsetAsync(ctx->pcursor, 0, sizeof(uint32_t), ctx->stream);
+                rtd::PersistArgs pa{};
+                pa.cursor = ctx->pcursor; pa.worklist = ctx->worklist; pa.wl_count = ctx->pcursor + 1;
+                pa.npix_pad = ctx->npix_pad; pa.sample0 = s0; pa.nsamples = ns; pa.threshold = ctx->persist_threshold;
+                pa.nthreads = (uint32_t)ctx->num_cus * 1024u; pa.stack = ctx->pstack;
+                pa.phx = ctx->phx; pa.phy = ctx->phy; pa.phz = ctx->phz; pa.pinfo = ctx->pinfo;
+                pa.sun_lut = ctx->sun_lut; pa.dif_lut = ctx->dif_lut;
+                pa.plx = ctx->pplx; pa.ply = ctx->pply; pa.plz = ctx->pplz; pa.counters = ctx->d_counters;
+                if (e == hipSuccess) {
+                    LaunchTimer t(ctx, 0);
+                    e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->num_cus, ctx->stream);
+                }
+                if (e == hipSuccess) {
+                    LaunchTimer t(ctx, 1);
+                    e = rtd::launch_accumulate_paths(ctx->pplx, ctx->pply, ctx->pplz, ctx->worklist, ctx->pcursor + 1, ctx->npix_pad, ns,
+                                                     s0 == 0, cache, ctx->pacc, ctx->stream);
+                }
+            }
+        }
+        if (e == hipSuccess) {
+            LaunchTimer t(ctx, 1);
+            e = rtd::launch_resolve(f, ctx->pacc, planes_of(ctx), ctx->npix_pad, ctx->stream);
+        }
+        if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("persistent path: ") + hipGetErrorString(e));
     } else {
         rc = draw_wavefront(ctx, f);
     }

@@ -224,7 +224,8 @@ __device__ inline Hit trace_ray_generic(const Scene& sc, const Frame& f, vec3 or
         float t; uint32_t n;
         if (lx < ly) { if (lx < lz) { t = lx; n = nx; } else { t = lz; n = nz; } }
         else         { if (ly < lz) { t = ly; n = ny; } else { t = lz; n = nz; } }          // :120-136
-        h.position = vadd(h.position, vscale(direction, t));
+        h.position = v3(rtm_fma(direction.x, t, h.position.x), rtm_fma(direction.y, t, h.position.y),
+                        rtm_fma(direction.z, t, h.position.z));   // fused (rt_math.h contract)
         h.normal = n;
         step = fetch_step_global(sc, h.position, &h.border);                               // :137
         if (rtm_abs(h.position.x - f.lr[0]) >= half || rtm_abs(h.position.y - f.lr[1]) >= half ||
@@ -278,6 +279,26 @@ __device__ __forceinline__ void store_lighting(const Planes& pl, uint32_t i, vec
     q.x = (uint16_t)rtm_unorm(lv.x, 65535.0f); q.y = (uint16_t)rtm_unorm(lv.y, 65535.0f);
     q.z = (uint16_t)rtm_unorm(lv.z, 65535.0f); q.w = (uint16_t)rtm_unorm(lv.w, 65535.0f);
     reinterpret_cast<ushort4*>(pl.lighting_rgba16)[i] = q;
+}
+
+// ---- light unwinding shared by all kernels ----------------------------------------------------------------
+// L_j = [sun_j] S + (dif_j air ? sky : (j < D ? L_{j+1} * albedo_{j+1} + emission : 0))  — the body of
+// raytrace.comp:324-349 generalised to `depth` levels; evaluated innermost-first so the fp32 operation order is
+// exactly the shader's (light2 *= albedo2; light2 += emission; light += light2).
+template <typename AlbedoAt>
+__device__ __forceinline__ vec3 unwind_light(int K, uint32_t sunbits, bool terminal_sky, vec3 sky, vec3 sunlight,
+                                             AlbedoAt albedo_at /* level j in 1..K-1 -> packed material of surface j+1 */) {
+    vec3 L = v3(0.0f, 0.0f, 0.0f);
+    if (sunbits >> (K - 1) & 1u) L = vadd(L, sunlight);
+    if (terminal_sky) L = vadd(L, sky);
+    for (int j = K - 1; j >= 1; j--) {
+        vec3 light2 = vmul(L, albedo_of(albedo_at(j)));
+        light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));     // + dif.emission, always vec3(0) (raytrace.comp:155)
+        vec3 acc = v3(0.0f, 0.0f, 0.0f);
+        if (sunbits >> (j - 1) & 1u) acc = vadd(acc, sunlight);
+        L = vadd(acc, light2);
+    }
+    return L;
 }
 
 // ---- exact integer counters ------------------------------------------------------------------------------

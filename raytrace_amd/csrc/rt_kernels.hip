@@ -55,28 +55,6 @@ __global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict_
 }
 
 // =====================================================================================================
-// Light unwinding shared by both pipelines
-// =====================================================================================================
-// L_j = [sun_j] S + (dif_j air ? sky : (j < D ? L_{j+1} * albedo_{j+1} + emission : 0))  — the body of
-// raytrace.comp:324-349 generalised to `depth` levels; evaluated innermost-first so the fp32 operation order is
-// exactly the shader's (light2 *= albedo2; light2 += emission; light += light2).
-template <typename AlbedoAt>
-__device__ __forceinline__ vec3 unwind_light(int K, uint32_t sunbits, bool terminal_sky, vec3 sky, vec3 sunlight,
-                                             AlbedoAt albedo_at /* level j in 1..K-1 -> packed material of surface j+1 */) {
-    vec3 L = v3(0.0f, 0.0f, 0.0f);
-    if (sunbits >> (K - 1) & 1u) L = vadd(L, sunlight);
-    if (terminal_sky) L = vadd(L, sky);
-    for (int j = K - 1; j >= 1; j--) {
-        vec3 light2 = vmul(L, albedo_of(albedo_at(j)));
-        light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));     // + dif.emission, always vec3(0) (raytrace.comp:155)
-        vec3 acc = v3(0.0f, 0.0f, 0.0f);
-        if (sunbits >> (j - 1) & 1u) acc = vadd(acc, sunlight);
-        L = vadd(acc, light2);
-    }
-    return L;
-}
-
-// =====================================================================================================
 // k_mega — one thread per pixel
 // =====================================================================================================
 template <bool COUNT>
@@ -298,7 +276,7 @@ __global__ __launch_bounds__(1024, 4) void k_trace(Scene sc, Frame f, TraceArgs 
                 const bool useZ = !(m1 < tz);
                 const float t = useZ ? tz : m1;
                 axis = useZ ? 2u : (xy ? 0u : 1u);
-                px = px + dx * t; py = py + dy * t; pz = pz + dz * t;
+                px = __builtin_fmaf(dx, t, px); py = __builtin_fmaf(dy, t, py); pz = __builtin_fmaf(dz, t, pz);   // fused (rt_math.h contract)
                 n++;
                 ux = px + half; uy = py + half; uz = pz + half;
                 // ---- sky test (:138-145), then address of the next fetch ------------------------------

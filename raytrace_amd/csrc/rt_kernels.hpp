@@ -46,6 +46,42 @@ struct ShadeArgs {
     DevCounters* counters;
 };
 
+// k_primary (rt_persist.hip): primary prepass.  Arrays are indexed by local pixel.
+struct PrimaryArgs {
+    float *phx, *phy, *phz;     // primary hit position (with the 0.001 face offset) of queued pixels
+    uint32_t* pinfo;            // material[20:0] | face id << 24
+    uint32_t* worklist;         // local pixel ids that need shadow/diffuse rays
+    uint32_t* wl_count;         // zero before launch
+    float4* acc;                // per-pixel light sum of finished (sky / depth 0) pixels
+    DevCounters* counters;
+};
+// k_persist (rt_persist.hip): persistent path kernel.  Work item r = sample_in_batch * nwork + w.
+struct PersistArgs {
+    uint32_t* cursor;           // next path to hand out (zero before launch)
+    const uint32_t* worklist;   // CACHE: pixels queued by k_primary
+    const uint32_t* wl_count;   // CACHE: number of queued pixels (nwork)
+    uint32_t npix_pad;          // CACHE=false: nwork = all local pixels (padded to whole 8x8 tiles)
+    uint32_t sample0, nsamples; // samples of this batch: sample0 .. sample0+nsamples-1
+    uint32_t threshold;         // parked lanes per wave that trigger a transition pass (1..64)
+    uint32_t nthreads;          // grid size in threads (stride of the albedo stack)
+    uint32_t* stack;            // [(depth-1)][nthreads] packed material of surface j+1 (only touched when depth >= 2)
+    const float *phx, *phy, *phz;   // CACHE: primary hit per local pixel
+    const uint32_t* pinfo;
+    const float4* sun_lut;      // [2*65536] per-frame shadow-ray table: direction, 1/|direction|
+    const float4* dif_lut;      // [3*6*65536] diffuse-ray table per (face, noise byte pair): dir, normalized dir, 1/|dir|
+    float *plx, *ply, *plz;     // [nsamples * nwork] light of each path (SoA)
+    DevCounters* counters;
+};
+hipError_t launch_accumulate_paths(const float* plx, const float* ply, const float* plz, const uint32_t* worklist,
+                                   const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool cache,
+                                   float4* acc, hipStream_t st);
+hipError_t launch_sphere_lut(float4* lut, hipStream_t st);
+hipError_t launch_dif_lut(const float4* sphere, float4* lut, hipStream_t st);
+hipError_t launch_sun_lut(const Frame& f, float4* lut, hipStream_t st);
+hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count, hipStream_t st);
+hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
+                          int nworkgroups, hipStream_t st);
+
 hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
                           uint32_t* coarse, uint32_t* bad_flag, hipStream_t st);
 hipError_t launch_mega(const Scene& sc, const Frame& f, const Planes& pl, DevCounters* cn, bool count, hipStream_t st);

@@ -1,0 +1,506 @@
+// rt_persist.hip — the production kernels of the ray-trace path.
+//
+//   k_primary : one thread per pixel (8x8 tile per wave, so the wave's rays are coherent): primary ray, the five
+//               primary-only G-buffer planes, finished lighting for sky pixels, and a __ballot-compacted worklist of
+//               the pixels that still need shadow/diffuse rays together with their primary hits (SoA in HBM).
+//   k_persist : persistent wave64 path kernel.  One 1024-thread workgroup per CU stays resident for the frame and
+//               shares a 128 KiB nibble map of the scene in LDS.  A lane owns one path (pixel, sample) at a time and
+//               keeps its whole state in registers: level, shadow bits, and the level's TWO rays (shadow + diffuse)
+//               which it walks together.  All lanes run the same DDA step loop.  A lane whose rays have ended parks;
+//               when `threshold` lanes of the wave are parked (__ballot) the wave runs ONE transition pass for all of
+//               them — consume the results, shade, start the next level (directions come from tables), or finish
+//               the path and pull the next one from the global cursor (one atomicAdd per wave, ballot-ranked) — so
+//               shading runs on a well-filled wave and the step loop on compacted work.  Per path only 12 bytes of
+//               light go to HBM (SoA, coalesced); k_accumulate_paths adds a pixel's samples in order.
+//
+// The primary ray does not depend on the seed (raytrace.comp:306-320 reads no noise), so with RT_FLAG_CACHE_PRIMARY
+// it is traced once per pixel (k_primary) and every sample starts at its first shadow ray.  Without the flag
+// k_persist<CACHE=false> walks every pixel itself and re-traces the primary ray for each sample (the reference's
+// ray count; used for counter parity).
+//
+// Values are those of raytrace.comp; only the grouping of the work differs (see the loop note in rt_kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include "rt_device.hpp"
+#include "rt_kernels.hpp"
+
+namespace rtd {
+
+// Unit-sphere point of diffuse_direction (raytrace.comp:190-197) for every (noise.r, noise.g) byte pair.
+__global__ __launch_bounds__(256) void k_build_sphere_lut(float4* __restrict__ lut) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly 65536
+    const float nr = (float)(i & 255u) / 255.0f, ng = (float)(i >> 8) / 255.0f;
+    float theta1 = RTM_PI * 2.0f * nr;
+    float theta2 = rtm_acos(1.0f - 2.0f * ng);
+    float s1, c1, s2, c2;
+    rtm_sincos(theta1, &s1, &c1);
+    rtm_sincos(theta2, &s2, &c2);
+    lut[i] = make_float4(s1 * s2, c1 * s2, c2, 0.0f);
+}
+
+// Whole head of trace_ray for a diffuse ray, per (face id, noise byte pair): entry 3i = diffuse_direction (the
+// sample_sky argument, raytrace.comp:331), 3i+1 = normalize of it (:83), 3i+2 = length_per_axis (:88).
+__global__ __launch_bounds__(256) void k_build_dif_lut(const float4* __restrict__ sphere, float4* __restrict__ lut) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly 6 * 65536
+    const uint32_t normal = i >> 16;
+    const float4 p = sphere[i & 0xFFFFu];
+    vec3 d = v3(p.x, p.y, p.z);
+    if (normal == 0) d.x += 1.0f;
+    else if (normal == 1) d.x -= 1.0f;
+    else if (normal == 2) d.y += 1.0f;
+    else if (normal == 3) d.y -= 1.0f;
+    else if (normal == 4) d.z += 1.0f;
+    else d.z -= 1.0f;
+    const vec3 dd = vnormalize(d);          // diffuse_direction's return value (:211)
+    const vec3 d2 = vnormalize(dd);         // trace_ray's own normalize (:83)
+    lut[3 * i] = make_float4(dd.x, dd.y, dd.z, 0.0f);
+    lut[3 * i + 1] = make_float4(d2.x, d2.y, d2.z, 0.0f);
+    lut[3 * i + 2] = make_float4(1.0f / rtm_abs(d2.x), 1.0f / rtm_abs(d2.y), 1.0f / rtm_abs(d2.z), 0.0f);
+}
+
+__device__ __forceinline__ vec3 diffuse_direction_lut(const float4* __restrict__ lut, uint32_t normal, uint32_t nvtex) {
+    const float4 p = lut[nvtex & 0xFFFFu];
+    vec3 d = v3(p.x, p.y, p.z);
+    if (normal == 0) d.x += 1.0f;
+    else if (normal == 1) d.x -= 1.0f;
+    else if (normal == 2) d.y += 1.0f;
+    else if (normal == 3) d.y -= 1.0f;
+    else if (normal == 4) d.z += 1.0f;
+    else if (normal == 5) d.z -= 1.0f;
+    return vnormalize(d);
+}
+
+// =====================================================================================================
+// k_primary
+// =====================================================================================================
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_primary(Scene sc, Frame f, Planes pl, PrimaryArgs a) {
+    const uint32_t lp = blockIdx.x * 256u + threadIdx.x;
+    PixelId pix = pixel_of_local(f, lp);
+    bool queue = false;
+    unsigned long long c_prim = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0, c_pix = 0;
+    if (pix.inside) {
+        vec3 start, dir;
+        primary_ray(f, pix.px, pix.py, &start, &dir);
+        Hit h = trace_ray_generic(sc, f, start, dir);
+        if (COUNT) {
+            c_prim++; c_pix++; c_iter += h.iterations; c_border += h.border; c_limit += h.limit_exit;
+            if (h.air) c_sky++; else if (!h.limit_exit) c_hits++;
+        }
+        store_primary_planes(pl, pix.out_index, f, dir, h.air, h.normal, h.material, h.position);
+        if (h.air || f.depth < 1) {
+            // every sample of this pixel has the same light (no noise is read): sum it spp times like the shader's
+            // spp frames would, then store
+            vec3 light = v3(0.0f, 0.0f, 0.0f);
+            if (h.air) light = sample_sky(dir, ld3(f.sunangle), ld3(f.sunlight), true);            // raytrace.comp:321-322
+            vec3 sum = v3(0.0f, 0.0f, 0.0f);
+            for (int s = 0; s < f.spp; s++) sum = vadd(sum, light);
+            a.acc[lp] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        } else {
+            a.phx[lp] = h.position.x; a.phy[lp] = h.position.y; a.phz[lp] = h.position.z;
+            a.pinfo[lp] = h.material | (h.normal << 24);
+            queue = true;
+        }
+    }
+    // worklist append: one atomic per wave, ballot-ranked slots
+    const uint64_t m = __ballot(queue);
+    if (m) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(a.wl_count, (uint32_t)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m), 64);
+        if (queue) a.worklist[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = lp;
+    }
+    if (COUNT) {
+        DevCounters* cn = a.counters;
+        wave_add(&cn->rays, c_prim); wave_add(&cn->rays_primary, c_prim); wave_add(&cn->iterations, c_iter);
+        wave_add(&cn->minefield_fetches, c_prim + c_iter); wave_add(&cn->hits, c_hits); wave_add(&cn->material_fetches, c_hits);
+        wave_add(&cn->sky_exits, c_sky); wave_add(&cn->limit_exits, c_limit); wave_add(&cn->border_fetches, c_border);
+        wave_add(&cn->pixels, c_pix);
+    }
+}
+
+// =====================================================================================================
+// k_persist
+// =====================================================================================================
+enum : uint32_t { PH_EMPTY = 0, PH_PRIMARY = 1, PH_SUN = 2, PH_DIF = 3 };
+enum : uint32_t { PX_AIR = 0, PX_HIT = 1, PX_LIMIT = 2, PX_SPECIAL = 3 };
+
+// Shadow rays depend only on the frame's sun vector and the (noise.r, noise.g) byte pair (raytrace.comp:185-187), so
+// the whole head of trace_ray for them — normalize (trace_sun), normalize again (:83), 1/|d| (:88) — is tabulated once
+// per frame: entry 2i = direction, 2i+1 = length_per_axis.
+__global__ __launch_bounds__(256) void k_build_sun_lut(Frame f, float4* __restrict__ lut) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly 65536
+    const float nr = (float)(i & 255u) / 255.0f, ng = (float)(i >> 8) / 255.0f;
+    const vec3 d = vnormalize(sun_ray_direction(ld3(f.sunangle), nr, ng));
+    lut[2 * i] = make_float4(d.x, d.y, d.z, 0.0f);
+    lut[2 * i + 1] = make_float4(1.0f / rtm_abs(d.x), 1.0f / rtm_abs(d.y), 1.0f / rtm_abs(d.z), 0.0f);
+}
+
+// One ray in flight.  A lane carries two: slot S walks the level's shadow ray, slot F its diffuse ray (or, with
+// CACHE=false, the primary ray).  The two rays of a level are independent (raytrace.comp:325 and :330 both start from
+// the same surface), so stepping them together doubles the memory-level parallelism of the dependent fetch chain and
+// halves the number of transition passes.
+struct RaySlot {
+    float px, py, pz, dx, dy, dz, lx, ly, lz, ux, uy, uz;
+    uint32_t sgnx, sgny, sgnz, vox, n, axis, kind;
+    bool tracing, valid, fresh, fresh_invalid;
+};
+
+template <bool LRZ, bool COUNT, bool CACHE>
+__global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes pl, PersistArgs a) {
+    __shared__ uint32_t s_coarse[kCoarseWords];
+    // work items: path r = sample_in_batch * nwork + w, w = worklist slot (CACHE) or local pixel (CACHE=false)
+    const uint32_t nwork = CACHE ? *a.wl_count : a.npix_pad;
+    const uint32_t nitems = nwork * a.nsamples;
+    if (nitems == 0u) return;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.coarse);
+        uint4* dst = reinterpret_cast<uint4*>(s_coarse);
+        for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t threshold = a.threshold;
+    const float half = (float)kR / 2;
+    const vec3 sunangle = ld3(f.sunangle), sunlight = ld3(f.sunlight);
+    const uint32_t D = (uint32_t)f.depth;
+
+    RaySlot S, F;
+    S.px = S.py = S.pz = S.dx = S.dy = S.lx = S.ly = S.lz = S.ux = S.uy = S.uz = 0.0f; S.dz = 1.0f;
+    S.sgnx = S.sgny = S.sgnz = S.vox = S.n = 0u; S.axis = 2u; S.kind = PX_HIT;
+    S.tracing = false; S.valid = true; S.fresh = false; S.fresh_invalid = false;
+    F = S;
+    // ---- path state ----
+    uint32_t phase = PH_EMPTY;                // PH_EMPTY, PH_PRIMARY (F only, CACHE=false), PH_DIF (= a level: S and F)
+    uint32_t item = 0, lp = 0, samp = 0, level = 0, sunbits = 0;
+    float ddx = 0, ddy = 0, ddz = 0;          // diffuse direction in flight (sample_sky argument)
+    float nox = 0, noy = 0;                   // noise_offset of the path (raytrace.comp:298-304)
+    bool exhausted = false;
+    constexpr uint32_t kChunk = 512;
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of the path range
+
+    unsigned long long c_prim = 0, c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0,
+                       c_noise = 0, c_pix = 0;
+
+    // ---- head of trace_ray (:83-107) ---------------------------------------------------------------------------
+    // origin part, shared by the two rays of a level (same surface point): texel of the first fetch (:106, Q6)
+    auto arm = [&](RaySlot& r, vec3 ro, bool ok, uint32_t vox0) {   // needs r.d*, r.l* set
+        r.px = ro.x; r.py = ro.y; r.pz = ro.z;
+        r.sgnx = r.dx > 0.0f ? 0x80000000u : 0u; r.sgny = r.dy > 0.0f ? 0x80000000u : 0u;           // :94-98
+        r.sgnz = r.dz > 0.0f ? 0x80000000u : 0u;
+        r.ux = ro.x + half; r.uy = ro.y + half; r.uz = ro.z + half;
+        r.valid = ok; r.fresh_invalid = !ok; r.vox = vox0;
+        r.n = 0; r.axis = 2; r.fresh = true; r.kind = PX_HIT;
+        if (r.dx != r.dx || r.dy != r.dy || r.dz != r.dz) { r.kind = PX_SPECIAL; r.n = 1; r.tracing = false; }   // NaN direction
+        else r.tracing = true;
+    };
+    auto set_dir = [&](RaySlot& r, vec3 rd) {
+        vec3 d = vnormalize(rd);                                                                     // :83
+        r.dx = d.x; r.dy = d.y; r.dz = d.z;
+        r.lx = 1.0f / rtm_abs(d.x); r.ly = 1.0f / rtm_abs(d.y); r.lz = 1.0f / rtm_abs(d.z);           // :88
+    };
+
+    // ---- one DDA step: fetch value `step` already looked up -------------------------------------------------------
+    auto advance = [&](RaySlot& r, uint32_t step) {
+        if (!r.valid) step = 0u;
+        if (step == 0u) {
+            r.kind = r.fresh ? PX_SPECIAL : PX_HIT;   // a fresh ray on a 0 has step_size 0 => mod(x,0) = NaN (defined outcome)
+            if (r.fresh) r.n = 1;
+            r.tracing = false;
+        } else if (r.n == (uint32_t)RT_TRACE_LIMIT) {
+            r.kind = PX_LIMIT; r.tracing = false;                                                   // :109 (Q8)
+        } else {
+            r.fresh = false;
+            // advance (:119-136)
+            const uint32_t sb = (step << 23) + (126u << 23);          // float((1 << step) / 2)
+            const float sz = __builtin_bit_cast(float, sb);
+            const float is = __builtin_bit_cast(float, 0x7F000000u - sb);   // exactly 1/sz
+            const float qx = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r.ux) ^ r.sgnx);
+            const float qy = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r.uy) ^ r.sgny);
+            const float qz = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r.uz) ^ r.sgnz);
+            const float mx = __builtin_fmaf(-sz, rtm_floor(qx * is), qx);   // == q - sz*floor(q/sz): both products exact
+            const float my = __builtin_fmaf(-sz, rtm_floor(qy * is), qy);
+            const float mz = __builtin_fmaf(-sz, rtm_floor(qz * is), qz);
+            const float tx = (0.0001f + mx) * r.lx, ty = (0.0001f + my) * r.ly, tz = (0.0001f + mz) * r.lz;
+            const bool xy = tx < ty;
+            const float m1 = xy ? tx : ty;
+            const bool useZ = !(m1 < tz);
+            const float t = useZ ? tz : m1;
+            r.axis = useZ ? 2u : (xy ? 0u : 1u);
+            r.px = __builtin_fmaf(r.dx, t, r.px); r.py = __builtin_fmaf(r.dy, t, r.py); r.pz = __builtin_fmaf(r.dz, t, r.pz);   // fused (rt_math.h contract)
+            r.n++;
+            r.ux = r.px + half; r.uy = r.py + half; r.uz = r.pz + half;
+            // sky test (:138-145), then the address of the next fetch
+            const bool sky = rtm_abs(r.px - f.lr[0]) >= half || rtm_abs(r.py - f.lr[1]) >= half || rtm_abs(r.pz - f.lr[2]) >= half;
+            if (sky) {
+                r.kind = PX_AIR; r.tracing = false;
+            } else if (LRZ) {
+                const int ix = (int)r.ux & 255, iy = (int)r.uy & 255, iz = (int)r.uz & 255;
+                r.vox = swizzled_index(ix, iy, iz);
+            } else {
+                int ix, iy, iz;
+                r.valid = wrap_texel(v3(r.px, r.py, r.pz), &ix, &iy, &iz);
+                if (COUNT && !r.valid) c_border++;
+                r.vox = swizzled_index(ix, iy, iz);
+            }
+        }
+    };
+    auto tally = [&](const RaySlot& r) {   // exact counters of one finished ray
+        c_iter += r.n;
+        if (r.kind == PX_AIR) {
+            c_sky++;
+            int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
+            if (!wrap_texel(v3(r.px, r.py, r.pz), &tx, &ty, &tz)) c_border++;
+        } else if (r.kind == PX_LIMIT) c_limit++;
+        else c_hits++;
+        if (r.kind == PX_SPECIAL) c_border += 1u + (r.fresh_invalid ? 1u : 0u);
+        else if (r.fresh_invalid) c_border++;
+    };
+
+    for (;;) {
+        // Lanes whose rays have all ended park; when `threshold` of them are parked the wave runs one transition pass.
+        const uint64_t m_busy = __ballot(S.tracing || F.tracing);
+        const uint64_t m_wait = __ballot(!(S.tracing || F.tracing) && (phase != PH_EMPTY || !exhausted));
+        const uint32_t n_busy = (uint32_t)__popcll(m_busy), n_wait = (uint32_t)__popcll(m_wait);
+        if (n_wait < threshold && n_busy != 0u) {
+            // ---- step loop: run until enough further lanes have parked -----------------------------------------
+            const uint32_t need = threshold - n_wait;   // >= 1
+            const uint32_t target = n_busy > need ? n_busy - need : 0u;
+            do {
+                // fetches of both slots first (:106 for a fresh ray, :137 otherwise), so their latencies overlap
+                const uint32_t bS = S.vox >> 6, bF = F.vox >> 6;
+                const uint32_t wS = s_coarse[bS >> 3], wF = s_coarse[bF >> 3];
+                uint32_t stS = (wS >> ((bS & 7u) << 2)) & 15u, stF = (wF >> ((bF & 7u) << 2)) & 15u;
+                const bool gS = S.tracing && stS == kNibMixed, gF = F.tracing && stF == kNibMixed;
+                uint8_t byS = 0, byF = 0;
+                if (gS) byS = sc.mine[S.vox];
+                if (gF) byF = sc.mine[F.vox];
+                if (gS) stS = byS;
+                if (gF) stF = byF;
+                if (S.tracing) advance(S, stS);
+                if (F.tracing) advance(F, stF);
+            } while ((uint32_t)__popcll(__ballot(S.tracing || F.tracing)) > target);
+            continue;
+        }
+        if (n_wait == 0u) break;   // nothing in flight, nothing parked, no paths left
+
+        // =========================== transition pass ===========================================================
+        const bool mine = !(S.tracing || F.tracing) && phase != PH_EMPTY;
+        bool path_done = false, begin_level = false, need_primary = false;
+        vec3 light = v3(0, 0, 0);
+        float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
+        uint32_t snormal = 0;
+        if (mine) {
+            // Diffuse / primary result.  The hit texel is the texel of the last fetch (same position, same wrap:
+            // mod((p+128)/256,1)*256 and mod(p+128,256) agree bit for bit), so the material is mat[vox] (:150-154); the
+            // position gets the 0.001 face offset (:166-180).
+            const bool air = F.kind == PX_AIR;
+            const uint32_t nrm = F.axis == 0 ? (F.dx > 0.0f ? 1u : 0u) : (F.axis == 1 ? (F.dy > 0.0f ? 3u : 2u) : (F.dz > 0.0f ? 5u : 4u));
+            uint32_t material = 0;
+            if (F.kind == PX_HIT && F.valid) material = sc.mat[F.vox];
+            float hx = F.px, hy = F.py, hz = F.pz;
+            if (F.kind == PX_SPECIAL) { hx = hy = hz = __builtin_nanf(""); }
+            const float off = 0.001f;
+            if (nrm == 0) hx += off; else if (nrm == 1) hx -= off;
+            else if (nrm == 2) hy += off; else if (nrm == 3) hy -= off;
+            else if (nrm == 4) hz += off; else hz -= off;
+            if (COUNT) tally(F);
+            if (!CACHE && phase == PH_PRIMARY) {
+                PixelId pix = pixel_of_local(f, lp);
+                vec3 pstart, pdir;
+                primary_ray(f, pix.px, pix.py, &pstart, &pdir);
+                if (samp == 0u) {
+                    store_primary_planes(pl, pix.out_index, f, pdir, air, nrm, material, v3(hx, hy, hz));
+                    if (COUNT) c_pix++;
+                }
+                if (air) {
+                    light = sample_sky(pdir, sunangle, sunlight, true);                            // :321-322
+                    path_done = true;
+                } else if (D < 1u) {
+                    path_done = true;
+                } else {
+                    sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
+                    level = 1; sunbits = 0; begin_level = true;
+                }
+            } else {
+                // a level ended: shadow result (:326-328 / :338-340), then the diffuse result
+                if (COUNT) tally(S);
+                if (S.kind == PX_AIR) sunbits |= 1u << (level - 1);
+                if (air || level == D) {
+                    vec3 sky = v3(0, 0, 0);
+                    if (air) sky = sample_sky(v3(ddx, ddy, ddz), sunangle, sunlight, true);        // :331-332 / :343-345
+                    vec3 L1 = unwind_light((int)level, sunbits, air, sky, sunlight,
+                                           [&](int j) { return a.stack[(size_t)(j - 1) * a.nthreads + gtid]; });
+                    light = vadd(v3(0.0f, 0.0f, 0.0f), L1);
+                    path_done = true;
+                } else {
+                    a.stack[(size_t)(level - 1) * a.nthreads + gtid] = material;   // albedo of surface level+1
+                    sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
+                    level++; begin_level = true;
+                }
+            }
+            if (path_done) {   // the path's light; k_accumulate_paths adds the samples of a pixel in order
+                a.plx[item] = light.x; a.ply[item] = light.y; a.plz[item] = light.z;
+                phase = PH_EMPTY;
+            }
+        }
+        // empty lanes pull the next paths: the wave owns a chunk of kChunk consecutive paths (one atomicAdd on the global
+        // cursor per chunk — a single word saturates near 90 returning atomics/us) and deals them out ballot-ranked
+        if (!exhausted) {
+            const uint64_t want = __ballot(phase == PH_EMPTY);
+            const uint32_t nwant = (uint32_t)__popcll(want);
+            if (nwant) {
+                if (chunk_next >= chunk_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(a.cursor, kChunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    chunk_next = base;
+                    chunk_end = base + kChunk < nitems ? base + kChunk : nitems;
+                    if (base >= nitems) { exhausted = true; chunk_next = chunk_end = nitems; }
+                }
+                const uint32_t take = min(nwant, chunk_end - chunk_next);
+                const uint32_t first = chunk_next;
+                chunk_next += take;
+                if (phase == PH_EMPTY) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                    const uint32_t r = rank < take ? first + rank : nitems;
+                    if (r < nitems) {
+                        const uint32_t sb = r / nwork, w = r - sb * nwork;
+                        const uint32_t cand = CACHE ? a.worklist[w] : w;
+                        PixelId pix = pixel_of_local(f, cand);
+                        if (pix.inside) {     // (only CACHE=false can meet padding pixels of partial tiles)
+                            item = r; lp = cand; samp = a.sample0 + sb;
+                            // noise_offset of this path (:298-304); texture().r * 255.0 == the byte itself for all 256
+                            // values (tests/test_math_contract.py), so no divide
+                            const uint32_t seed = (f.seed + samp) % (uint32_t)RT_NOISE_BYTES;
+                            const uint32_t nb = noise_texel(sc, (float)(seed % RT_NOISE_SIZE), (float)(seed / RT_NOISE_SIZE));
+                            nox = (float)(nb & 0xFFu) + (float)(owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE);
+                            noy = (float)((nb >> 8) & 0xFFu) + (float)(owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE);
+                            if (CACHE) {
+                                sfx = a.phx[cand]; sfy = a.phy[cand]; sfz = a.phz[cand];
+                                snormal = (a.pinfo[cand] >> 24) & 7u;
+                                level = 1; sunbits = 0; begin_level = true;
+                            } else {
+                                need_primary = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // both rays of a level (:324-330 / :336-342): noise_value, shadow ray and diffuse ray from the tables
+        if (begin_level) {
+            const float add = (float)(level - 1) * (2.0f / (float)RT_NOISE_SIZE);
+            const uint32_t nvtex = noise_texel(sc, rtm_mod(nox + add, (float)RT_NOISE_SIZE), rtm_mod(noy + add, (float)RT_NOISE_SIZE));
+            if (COUNT) { c_noise++; c_shadow++; c_dif++; }
+            const vec3 ro = v3(sfx, sfy, sfz);
+            int ix, iy, iz;
+            const bool ok = wrap_texel(ro, &ix, &iy, &iz);
+            const uint32_t vox0 = swizzled_index(ix, iy, iz);
+            const float4 sd = a.sun_lut[2u * (nvtex & 0xFFFFu)], sl = a.sun_lut[2u * (nvtex & 0xFFFFu) + 1u];
+            S.dx = sd.x; S.dy = sd.y; S.dz = sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
+            arm(S, ro, ok, vox0);
+            const uint32_t di = 3u * ((snormal << 16) | (nvtex & 0xFFFFu));
+            const float4 dd = a.dif_lut[di], d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
+            ddx = dd.x; ddy = dd.y; ddz = dd.z;
+            F.dx = d2.x; F.dy = d2.y; F.dz = d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
+            arm(F, ro, ok, vox0);
+            phase = PH_DIF;
+        }
+        // primary ray of the pixel (:296-315), CACHE=false only
+        if (!CACHE && need_primary) {
+            PixelId pix = pixel_of_local(f, lp);
+            vec3 ro, rd;
+            primary_ray(f, pix.px, pix.py, &ro, &rd);
+            int ix, iy, iz;
+            const bool ok = wrap_texel(ro, &ix, &iy, &iz);
+            set_dir(F, rd);
+            arm(F, ro, ok, swizzled_index(ix, iy, iz));
+            phase = PH_PRIMARY;
+            if (COUNT) c_prim++;
+        }
+    }
+    if (COUNT) {
+        DevCounters* cn = a.counters;
+        const unsigned long long rays = c_prim + c_shadow + c_dif;
+        wave_add(&cn->rays, rays); wave_add(&cn->rays_primary, c_prim); wave_add(&cn->rays_shadow, c_shadow);
+        wave_add(&cn->rays_diffuse, c_dif); wave_add(&cn->iterations, c_iter); wave_add(&cn->minefield_fetches, rays + c_iter);
+        wave_add(&cn->hits, c_hits); wave_add(&cn->material_fetches, c_hits); wave_add(&cn->sky_exits, c_sky);
+        wave_add(&cn->limit_exits, c_limit); wave_add(&cn->border_fetches, c_border); wave_add(&cn->noise_fetches, c_noise);
+        wave_add(&cn->pixels, c_pix);
+    }
+}
+
+// acc[pixel] (+)= the batch's samples of that pixel, in sample order (deterministic fp32 sum; raytrace.comp has one
+// sample per frame, the sum over frames is the build's spp extension).
+template <bool CACHE>
+__global__ __launch_bounds__(256) void k_accumulate_paths(const float* __restrict__ plx, const float* __restrict__ ply,
+                                                          const float* __restrict__ plz, const uint32_t* __restrict__ worklist,
+                                                          const uint32_t* __restrict__ wl_count, uint32_t npix_pad,
+                                                          uint32_t nsamples, int first_batch, float4* __restrict__ acc) {
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nwork = CACHE ? *wl_count : npix_pad;
+    if (w >= nwork) return;
+    const uint32_t lp = CACHE ? worklist[w] : w;
+    float4 v = first_batch ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : acc[lp];
+    for (uint32_t b = 0; b < nsamples; b++) {
+        const size_t r = (size_t)b * nwork + w;
+        v.x = v.x + plx[r]; v.y = v.y + ply[r]; v.z = v.z + plz[r];
+    }
+    acc[lp] = v;
+}
+
+hipError_t launch_accumulate_paths(const float* plx, const float* ply, const float* plz, const uint32_t* worklist,
+                                   const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool cache,
+                                   float4* acc, hipStream_t st) {
+    if (npix_pad == 0) return hipSuccess;
+    dim3 grid((npix_pad + 255u) / 256u), block(256);
+    if (cache) hipLaunchKernelGGL(k_accumulate_paths<true>, grid, block, 0, st, plx, ply, plz, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, acc);
+    else hipLaunchKernelGGL(k_accumulate_paths<false>, grid, block, 0, st, plx, ply, plz, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, acc);
+    return hipGetLastError();
+}
+
+hipError_t launch_sun_lut(const Frame& f, float4* lut, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_sun_lut, dim3(65536 / 256), dim3(256), 0, st, f, lut);
+    return hipGetLastError();
+}
+
+hipError_t launch_sphere_lut(float4* lut, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_sphere_lut, dim3(65536 / 256), dim3(256), 0, st, lut);
+    return hipGetLastError();
+}
+
+hipError_t launch_dif_lut(const float4* sphere, float4* lut, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_dif_lut, dim3(6 * 65536 / 256), dim3(256), 0, st, sphere, lut);
+    return hipGetLastError();
+}
+
+hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count, hipStream_t st) {
+    const uint32_t npix_pad = (uint32_t)f.ntiles_local * 64u;
+    if (npix_pad == 0) return hipSuccess;
+    dim3 grid((npix_pad + 255u) / 256u), block(256);
+    if (count) hipLaunchKernelGGL(k_primary<true>, grid, block, 0, st, sc, f, pl, a);
+    else hipLaunchKernelGGL(k_primary<false>, grid, block, 0, st, sc, f, pl, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
+                          int nworkgroups, hipStream_t st) {
+    dim3 grid(nworkgroups), block(1024);
+    const bool lrz = f.lr_zero != 0;
+#define RT_LAUNCH_PERSIST(L, C, K) hipLaunchKernelGGL((k_persist<L, C, K>), grid, block, 0, st, sc, f, pl, a)
+    if (lrz) {
+        if (count) { if (cache) RT_LAUNCH_PERSIST(true, true, true); else RT_LAUNCH_PERSIST(true, true, false); }
+        else       { if (cache) RT_LAUNCH_PERSIST(true, false, true); else RT_LAUNCH_PERSIST(true, false, false); }
+    } else {
+        if (count) { if (cache) RT_LAUNCH_PERSIST(false, true, true); else RT_LAUNCH_PERSIST(false, true, false); }
+        else       { if (cache) RT_LAUNCH_PERSIST(false, false, true); else RT_LAUNCH_PERSIST(false, false, false); }
+    }
+#undef RT_LAUNCH_PERSIST
+    return hipGetLastError();
+}
+
+}  // namespace rtd
