@@ -46,32 +46,29 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--kernel", choices=["persistent", "wavefront", "mega"], default="persistent")
-    ap.add_argument("--cache-primary", action="store_true", help="trace the seed-independent primary ray once per pixel")
+    ap.add_argument("--no-cache-primary", dest="cache_primary", action="store_false",
+                    help="re-trace the (seed-independent) primary ray for every sample, like spp reference frames would")
+    ap.set_defaults(cache_primary=True)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     return ap.parse_args()
 
 
-def cpu_baseline(mats, mine, noise, u, width, height, depth, rows_hint):
-    """The CPU oracle (a port: the reference has no CPU renderer) timed on the host cores on a bounded sample:
-    one of the spp samples over a band of rows centred on the horizon, sized for roughly 10-20 s."""
+def cpu_baseline(mats, mine, noise, u, width, height, spp, depth, target_s=12.0):
+    """The CPU oracle (a port: the reference has no CPU renderer) timed on this host's cores on a
+    bounded sample of the same workload: the full frame at as many of the workload's samples as fit in ~target_s."""
     from oracle import pyoracle as po
     cores = os.cpu_count() or 1
-    # calibrate on 16 rows, then size the band
-    y_mid = height // 2
     t0 = time.perf_counter()
-    _, cn = po.render(mats, mine, noise, u, width, height, 1, depth, rows=(y_mid - 8, y_mid + 8))
-    dt = max(time.perf_counter() - t0, 1e-3)
-    rows = rows_hint if rows_hint > 0 else int(min(height, max(32, 16 * 12.0 / dt)))
-    rows -= rows % 2
-    y0 = max(0, y_mid - rows // 2)
-    y1 = min(height, y0 + rows)
+    _, cn = po.render(mats, mine, noise, u, width, height, 1, depth)          # calibration: 1 sample
+    dt1 = max(time.perf_counter() - t0, 1e-3)
+    n = int(max(1, min(spp, target_s / dt1)))
     t0 = time.perf_counter()
-    _, cn = po.render(mats, mine, noise, u, width, height, 1, depth, rows=(y0, y1))
+    _, cn = po.render(mats, mine, noise, u, width, height, n, depth)
     dt = time.perf_counter() - t0
     return {"value": round(cn.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "oracle (scalar fp32 C++, OpenMP dynamic over rows), %dx%d rows [%d,%d) of 1 sample (seed %d), depth %d: "
-                      "%d rays in %.2f s" % (width, height, y0, y1, u.seed, depth, cn.rays, dt)}
+            "sample": "oracle (scalar fp32 C++ restatement of raytrace.comp, OpenMP dynamic over rows, %d threads): %dx%d, "
+                      "%d of the %d samples (seeds %d..%d), depth %d: %d rays in %.2f s (every primary ray re-traced)"
+                      % (cores, width, height, n, spp, u.seed, u.seed + n - 1, depth, cn.rays, dt)}
 
 
 def main():
@@ -204,7 +201,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(trace_bytes_local / max(trace_launches // max(args.steps, 1), 1))},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mats, mine, noise, u, W, H, D, args.cpu_rows)
+            out["cpu_baseline"] = cpu_baseline(mats, mine, noise, u, W, H, SPP, D)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

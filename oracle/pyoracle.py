@@ -141,3 +141,35 @@ def pack_chunk(solid, packed):
     mine = np.zeros(64 ** 3, dtype=np.uint8)
     lib().rt_oracle_pack_chunk(_p(solid), _p(packed), _p(mats), _p(mine))
     return mats, mine
+
+
+_MATH_FN = {"sin": 0, "cos": 1, "acos": 2, "pow": 3, "mod": 4, "exp2": 5, "log2": 6, "sqrt": 7, "rcp": 8}
+
+
+def math(fn, x, y=None):
+    """Evaluate one function of the arithmetic contract (include/rt_math.h) elementwise on float32 arrays."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float32)
+    out = np.empty_like(x)
+    lib().rt_oracle_math(C.c_int(_MATH_FN[fn]), _p(x), _p(y), _p(out), C.c_size_t(x.size))
+    return out
+
+
+def normalize(v):
+    o = (C.c_float * 3)()
+    lib().rt_oracle_normalize((C.c_float * 3)(*v), o)
+    return np.array(o[:], dtype=np.float32)
+
+
+def unorm(x, maxv):
+    f = lib().rt_oracle_unorm
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_float, C.c_float]
+    return int(f(float(x), float(maxv)))
+
+
+def f2u16(x):
+    f = lib().rt_oracle_f2u16
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_float]
+    return int(f(float(x)))

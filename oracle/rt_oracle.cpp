@@ -443,6 +443,37 @@ int rt_oracle_render(const uint32_t* materials, const uint8_t* minefield, const 
 void rt_oracle_fetch_stats_begin(const uint8_t* uniform4) { g_uniform4 = uniform4; memset(g_fetch_hist, 0, sizeof(g_fetch_hist)); }
 void rt_oracle_fetch_stats_end(uint64_t* out64) { memcpy(out64, g_fetch_hist, sizeof(g_fetch_hist)); g_uniform4 = nullptr; }
 
+// ---- arithmetic-contract probes (tests/test_math_contract.py): fn 0 sin, 1 cos, 2 acos, 3 pow(x,y), 4 mod(x,y),
+// 5 exp2, 6 log2, 7 sqrt, 8 1/x ----
+void rt_oracle_math(int fn, const float* x, const float* y, float* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        switch (fn) {
+            case 0: out[i] = rtm_sin(x[i]); break;
+            case 1: out[i] = rtm_cos(x[i]); break;
+            case 2: out[i] = rtm_acos(x[i]); break;
+            case 3: out[i] = rtm_pow(x[i], y[i]); break;
+            case 4: out[i] = rtm_mod(x[i], y[i]); break;
+            case 5: out[i] = rtm_exp2(x[i]); break;
+            case 6: out[i] = rtm_log2_pos(x[i]); break;
+            case 7: out[i] = rtm_sqrt(x[i]); break;
+            default: out[i] = 1.0f / x[i]; break;
+        }
+    }
+}
+void rt_oracle_normalize(const float* v3, float* out3) {
+    rtm_vec3 o = rtm_normalize3({v3[0], v3[1], v3[2]});
+    out3[0] = o.x; out3[1] = o.y; out3[2] = o.z;
+}
+// Texel coordinate (one axis) of the level-`level` noise_value lookup for a given noise_offset component
+// (raytrace.comp:324,336), exactly as level_light() computes it.
+int32_t rt_oracle_noise_level_texel(float noise_offset, int level) {
+    float add = (float)(level - 1) * (2.0f / (float)RT_NOISE_SIZE);
+    float c = rtm_floor(rtm_mod(noise_offset + add, (float)RT_NOISE_SIZE));
+    return c < 0 ? 0 : (c > 511 ? 511 : (int32_t)c);
+}
+uint32_t rt_oracle_unorm(float x, float maxv) { return rtm_unorm(x, maxv); }
+uint32_t rt_oracle_f2u16(float x) { return rtm_f2u16(x); }
+
 // ---- single-function entry points for the known-answer tests ---------------------------------
 struct RtOracleHit {
     float albedo[3]; float emission[3]; int32_t air; float distance; uint32_t normal; float position[3];

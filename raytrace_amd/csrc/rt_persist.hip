@@ -78,6 +78,8 @@ __global__ __launch_bounds__(256) void k_primary(Scene sc, Frame f, Planes pl, P
     const uint32_t lp = blockIdx.x * 256u + threadIdx.x;
     PixelId pix = pixel_of_local(f, lp);
     bool queue = false;
+    vec3 qpos = v3(0, 0, 0);
+    uint32_t qnormal = 0;
     unsigned long long c_prim = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0, c_pix = 0;
     if (pix.inside) {
         vec3 start, dir;
@@ -97,19 +99,26 @@ __global__ __launch_bounds__(256) void k_primary(Scene sc, Frame f, Planes pl, P
             for (int s = 0; s < f.spp; s++) sum = vadd(sum, light);
             a.acc[lp] = make_float4(sum.x, sum.y, sum.z, 0.0f);
         } else {
-            a.phx[lp] = h.position.x; a.phy[lp] = h.position.y; a.phz[lp] = h.position.z;
-            a.pinfo[lp] = h.material | (h.normal << 24);
             queue = true;
+            qpos = h.position; qnormal = h.normal;
         }
     }
-    // worklist append: one atomic per wave, ballot-ranked slots
+    // worklist append: one atomic per wave, ballot-ranked slots; the record of slot w is SoA over w so that the path
+    // kernel's item fetch is coalesced and needs no pixel arithmetic
     const uint64_t m = __ballot(queue);
     if (m) {
         const uint32_t lane = threadIdx.x & 63u;
         uint32_t base = 0;
         if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(a.wl_count, (uint32_t)__popcll(m));
         base = __shfl(base, __builtin_ctzll(m), 64);
-        if (queue) a.worklist[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = lp;
+        if (queue) {
+            const uint32_t w = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            a.worklist[w] = lp;
+            a.phx[w] = qpos.x; a.phy[w] = qpos.y; a.phz[w] = qpos.z;
+            // face id, and the noise_offset terms gl_WorkGroupID.xy * 8 of the pixel (raytrace.comp:304)
+            a.pinfo[w] = (qnormal << 28) | (owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE) << 14 |
+                         (owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE);
+        }
     }
     if (COUNT) {
         DevCounters* cn = a.counters;
@@ -150,6 +159,7 @@ struct RaySlot {
 template <bool LRZ, bool COUNT, bool CACHE>
 __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes pl, PersistArgs a) {
     __shared__ uint32_t s_coarse[kCoarseWords];
+    __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
     // work items: path r = sample_in_batch * nwork + w, w = worklist slot (CACHE) or local pixel (CACHE=false)
     const uint32_t nwork = CACHE ? *a.wl_count : a.npix_pad;
     const uint32_t nitems = nwork * a.nsamples;
@@ -158,6 +168,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
         const uint4* src = reinterpret_cast<const uint4*>(sc.coarse);
         uint4* dst = reinterpret_cast<uint4*>(s_coarse);
         for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
+        if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
     }
     __syncthreads();
 
@@ -177,10 +188,11 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     uint32_t phase = PH_EMPTY;                // PH_EMPTY, PH_PRIMARY (F only, CACHE=false), PH_DIF (= a level: S and F)
     uint32_t item = 0, lp = 0, samp = 0, level = 0, sunbits = 0;
     float ddx = 0, ddy = 0, ddz = 0;          // diffuse direction in flight (sample_sky argument)
-    float nox = 0, noy = 0;                   // noise_offset of the path (raytrace.comp:298-304)
+    uint32_t nvtex = 0;                       // noise_value texel of the path (raytrace.comp:324,336)
     bool exhausted = false;
     constexpr uint32_t kChunk = 512;
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of the path range
+    uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot) of path chunk_next
 
     unsigned long long c_prim = 0, c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0,
                        c_noise = 0, c_pix = 0;
@@ -332,9 +344,19 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 if (air || level == D) {
                     vec3 sky = v3(0, 0, 0);
                     if (air) sky = sample_sky(v3(ddx, ddy, ddz), sunangle, sunlight, true);        // :331-332 / :343-345
-                    vec3 L1 = unwind_light((int)level, sunbits, air, sky, sunlight,
-                                           [&](int j) { return a.stack[(size_t)(j - 1) * a.nthreads + gtid]; });
-                    light = vadd(v3(0.0f, 0.0f, 0.0f), L1);
+                    // L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
+                    vec3 L = v3(0.0f, 0.0f, 0.0f);
+                    if (sunbits >> (level - 1) & 1u) L = vadd(L, sunlight);
+                    if (air) L = vadd(L, sky);
+                    for (uint32_t j = level - 1; j >= 1u; j--) {
+                        const uint32_t pm = a.stack[(size_t)(j - 1) * a.nthreads + gtid];
+                        vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
+                        light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
+                        vec3 acc = v3(0.0f, 0.0f, 0.0f);
+                        if (sunbits >> (j - 1) & 1u) acc = vadd(acc, sunlight);
+                        L = vadd(acc, light2);
+                    }
+                    light = vadd(v3(0.0f, 0.0f, 0.0f), L);
                     path_done = true;
                 } else {
                     a.stack[(size_t)(level - 1) * a.nthreads + gtid] = material;   // albedo of surface level+1
@@ -360,41 +382,51 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                     chunk_next = base;
                     chunk_end = base + kChunk < nitems ? base + kChunk : nitems;
                     if (base >= nitems) { exhausted = true; chunk_next = chunk_end = nitems; }
+                    chunk_sb = chunk_next / nwork; chunk_w = chunk_next - chunk_sb * nwork;   // once per chunk
                 }
                 const uint32_t take = min(nwant, chunk_end - chunk_next);
                 const uint32_t first = chunk_next;
                 chunk_next += take;
                 if (phase == PH_EMPTY) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-                    const uint32_t r = rank < take ? first + rank : nitems;
-                    if (r < nitems) {
-                        const uint32_t sb = r / nwork, w = r - sb * nwork;
-                        const uint32_t cand = CACHE ? a.worklist[w] : w;
-                        PixelId pix = pixel_of_local(f, cand);
-                        if (pix.inside) {     // (only CACHE=false can meet padding pixels of partial tiles)
-                            item = r; lp = cand; samp = a.sample0 + sb;
-                            // noise_offset of this path (:298-304); texture().r * 255.0 == the byte itself for all 256
-                            // values (tests/test_math_contract.py), so no divide
+                    if (rank < take) {
+                        // (sample-in-batch, slot) of path first+rank, stepped from the chunk's running position (no division)
+                        uint32_t sb = chunk_sb, w = chunk_w + rank;
+                        while (w >= nwork) { w -= nwork; sb++; }
+                        uint32_t wgx8 = 0, wgy8 = 0;
+                        bool ok = true;
+                        if (CACHE) {
+                            const uint32_t info = a.pinfo[w];
+                            sfx = a.phx[w]; sfy = a.phy[w]; sfz = a.phz[w];
+                            snormal = info >> 28; wgx8 = info & 0x3FFFu; wgy8 = (info >> 14) & 0x3FFFu;
+                        } else {
+                            PixelId pix = pixel_of_local(f, w);
+                            ok = pix.inside;           // padding pixels of partial tiles carry no path
+                            wgx8 = owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE;
+                            wgy8 = owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE;
+                        }
+                        if (ok) {
+                            item = first + rank; lp = w; samp = a.sample0 + sb;
+                            // noise_offset of this path (:298-304) and its noise_value texel (:324, :336).  The bytes are
+                            // exact integers in float (texture().r * 255.0 == the byte) and the per-level offset
+                            // (level-1) * 2/512 never reaches the next texel, so one integer lookup serves every level
+                            // (tests/test_math_contract.py::test_noise_value_texel_is_level_independent).
                             const uint32_t seed = (f.seed + samp) % (uint32_t)RT_NOISE_BYTES;
-                            const uint32_t nb = noise_texel(sc, (float)(seed % RT_NOISE_SIZE), (float)(seed / RT_NOISE_SIZE));
-                            nox = (float)(nb & 0xFFu) + (float)(owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE);
-                            noy = (float)((nb >> 8) & 0xFFu) + (float)(owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE);
-                            if (CACHE) {
-                                sfx = a.phx[cand]; sfy = a.phy[cand]; sfz = a.phz[cand];
-                                snormal = (a.pinfo[cand] >> 24) & 7u;
-                                level = 1; sunbits = 0; begin_level = true;
-                            } else {
-                                need_primary = true;
-                            }
+                            const uint32_t by = seed / RT_NOISE_SIZE;
+                            const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
+                            const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
+                            nvtex = sc.noise[ty * RT_NOISE_SIZE + tx];
+                            if (CACHE) { level = 1; sunbits = 0; begin_level = true; }
+                            else need_primary = true;
                         }
                     }
                 }
+                chunk_w += take;
+                while (chunk_w >= nwork) { chunk_w -= nwork; chunk_sb++; }
             }
         }
         // both rays of a level (:324-330 / :336-342): noise_value, shadow ray and diffuse ray from the tables
         if (begin_level) {
-            const float add = (float)(level - 1) * (2.0f / (float)RT_NOISE_SIZE);
-            const uint32_t nvtex = noise_texel(sc, rtm_mod(nox + add, (float)RT_NOISE_SIZE), rtm_mod(noy + add, (float)RT_NOISE_SIZE));
             if (COUNT) { c_noise++; c_shadow++; c_dif++; }
             const vec3 ro = v3(sfx, sfy, sfz);
             int ix, iy, iz;
