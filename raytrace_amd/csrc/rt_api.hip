@@ -70,7 +70,7 @@ struct RtContext {
     float4* sun_lut = nullptr;
     float4* dif_lut = nullptr;
     float4* pacc = nullptr;
-    float *pplx = nullptr, *pply = nullptr, *pplz = nullptr;
+    float4* ppl = nullptr;
     uint32_t persist_batch = 1;
     uint32_t persist_threshold = 32, persist_threshold_sun = 16;
     rtd::DevCounters* d_counters = nullptr;
@@ -319,18 +319,18 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         RT_HIP_CREATE(dev_alloc(c, &c->phz, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->pinfo, (size_t)c->npix_pad));
         RT_HIP_CREATE(dev_alloc(c, &c->sphere_lut, (size_t)65536));
         RT_HIP_CREATE(dev_alloc(c, &c->sun_lut, (size_t)2 * 65536));
-        RT_HIP_CREATE(dev_alloc(c, &c->dif_lut, (size_t)3 * 6 * 65536));
+        RT_HIP_CREATE(dev_alloc(c, &c->dif_lut, (size_t)4 * 6 * 65536));
         RT_HIP_CREATE(dev_alloc(c, &c->pacc, (size_t)c->npix_pad));
         {   // samples per k_persist launch: bounded by 2 GiB of per-path light and by 2^30 work items
             uint64_t np = c->npix_pad ? c->npix_pad : 1;
-            uint64_t B = (2ull << 30) / (12ull * np);
+            uint64_t B = (2ull << 30) / (16ull * np);
             if (B > (1ull << 30) / np) B = (1ull << 30) / np;
             if (const char* s = getenv("RT_PERSIST_BATCH")) { long long v = atoll(s); if (v > 0) B = (uint64_t)v; }
             if (B < 1) B = 1;
             if (B > (uint64_t)cfg->spp) B = (uint64_t)cfg->spp;
             c->persist_batch = (uint32_t)B;
             size_t n = (size_t)np * B;
-            RT_HIP_CREATE(dev_alloc(c, &c->pplx, n)); RT_HIP_CREATE(dev_alloc(c, &c->pply, n)); RT_HIP_CREATE(dev_alloc(c, &c->pplz, n));
+            RT_HIP_CREATE(dev_alloc(c, &c->ppl, n));
         }
         RT_HIP_CREATE(rtd::launch_sphere_lut(c->sphere_lut, c->own_stream));
         RT_HIP_CREATE(rtd::launch_dif_lut(c->sphere_lut, c->dif_lut, c->own_stream));
@@ -477,14 +477,14 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 pa.nthreads = (uint32_t)ctx->num_cus * 1024u; pa.stack = ctx->pstack;
                 pa.phx = ctx->phx; pa.phy = ctx->phy; pa.phz = ctx->phz; pa.pinfo = ctx->pinfo;
                 pa.sun_lut = ctx->sun_lut; pa.dif_lut = ctx->dif_lut;
-                pa.plx = ctx->pplx; pa.ply = ctx->pply; pa.plz = ctx->pplz; pa.counters = ctx->d_counters;
+                pa.pl = ctx->ppl; pa.counters = ctx->d_counters;
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 0);
                     e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->num_cus, ctx->stream);
                 }
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 1);
-                    e = rtd::launch_accumulate_paths(ctx->pplx, ctx->pply, ctx->pplz, ctx->worklist, ctx->pcursor + 1, ctx->npix_pad, ns,
+                    e = rtd::launch_accumulate_paths(ctx->ppl, ctx->worklist, ctx->pcursor + 1, ctx->npix_pad, ns,
                                                      s0 == 0, cache, ctx->pacc, ctx->stream);
                 }
             }

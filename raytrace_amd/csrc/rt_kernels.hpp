@@ -68,11 +68,11 @@ struct PersistArgs {
     const float *phx, *phy, *phz;   // CACHE: primary hit per local pixel
     const uint32_t* pinfo;
     const float4* sun_lut;      // [2*65536] per-frame shadow-ray table: direction, 1/|direction|
-    const float4* dif_lut;      // [3*6*65536] diffuse-ray table per (face, noise byte pair): dir, normalized dir, 1/|dir|
-    float *plx, *ply, *plz;     // [nsamples * nwork] light of each path (SoA)
+    const float4* dif_lut;      // [4*6*65536] diffuse-ray table, one 64-byte line per (face, noise byte pair): dir, normalized dir, 1/|dir|, pad
+    float4* pl;                 // [nsamples * nwork] light of each path (one 16-byte store per path)
     DevCounters* counters;
 };
-hipError_t launch_accumulate_paths(const float* plx, const float* ply, const float* plz, const uint32_t* worklist,
+hipError_t launch_accumulate_paths(const float4* pl, const uint32_t* worklist,
                                    const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool cache,
                                    float4* acc, hipStream_t st);
 hipError_t launch_sphere_lut(float4* lut, hipStream_t st);

@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void k_build_sphere_lut(float4* __restrict__ l
     lut[i] = make_float4(s1 * s2, c1 * s2, c2, 0.0f);
 }
 
-// Whole head of trace_ray for a diffuse ray, per (face id, noise byte pair): entry 3i = diffuse_direction (the
-// sample_sky argument, raytrace.comp:331), 3i+1 = normalize of it (:83), 3i+2 = length_per_axis (:88).
+// Whole head of trace_ray for a diffuse ray, per (face id, noise byte pair).  One 64-byte line per entry:
+// 4i = diffuse_direction (the sample_sky argument, raytrace.comp:331), 4i+1 = normalize of it (:83),
+// 4i+2 = length_per_axis (:88), 4i+3 = padding.
 __global__ __launch_bounds__(256) void k_build_dif_lut(const float4* __restrict__ sphere, float4* __restrict__ lut) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly 6 * 65536
     const uint32_t normal = i >> 16;
@@ -53,9 +54,10 @@ __global__ __launch_bounds__(256) void k_build_dif_lut(const float4* __restrict_
     else d.z -= 1.0f;
     const vec3 dd = vnormalize(d);          // diffuse_direction's return value (:211)
     const vec3 d2 = vnormalize(dd);         // trace_ray's own normalize (:83)
-    lut[3 * i] = make_float4(dd.x, dd.y, dd.z, 0.0f);
-    lut[3 * i + 1] = make_float4(d2.x, d2.y, d2.z, 0.0f);
-    lut[3 * i + 2] = make_float4(1.0f / rtm_abs(d2.x), 1.0f / rtm_abs(d2.y), 1.0f / rtm_abs(d2.z), 0.0f);
+    lut[4 * i] = make_float4(dd.x, dd.y, dd.z, 0.0f);
+    lut[4 * i + 1] = make_float4(d2.x, d2.y, d2.z, 0.0f);
+    lut[4 * i + 2] = make_float4(1.0f / rtm_abs(d2.x), 1.0f / rtm_abs(d2.y), 1.0f / rtm_abs(d2.z), 0.0f);
+    lut[4 * i + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 __device__ __forceinline__ vec3 diffuse_direction_lut(const float4* __restrict__ lut, uint32_t normal, uint32_t nvtex) {
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 }
             }
             if (path_done) {   // the path's light; k_accumulate_paths adds the samples of a pixel in order
-                a.plx[item] = light.x; a.ply[item] = light.y; a.plz[item] = light.z;
+                a.pl[item] = make_float4(light.x, light.y, light.z, 0.0f);
                 phase = PH_EMPTY;
             }
         }
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             const float4 sd = a.sun_lut[2u * (nvtex & 0xFFFFu)], sl = a.sun_lut[2u * (nvtex & 0xFFFFu) + 1u];
             S.dx = sd.x; S.dy = sd.y; S.dz = sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
             arm(S, ro, ok, vox0);
-            const uint32_t di = 3u * ((snormal << 16) | (nvtex & 0xFFFFu));
+            const uint32_t di = 4u * ((snormal << 16) | (nvtex & 0xFFFFu));
             const float4 dd = a.dif_lut[di], d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
             ddx = dd.x; ddy = dd.y; ddz = dd.z;
             F.dx = d2.x; F.dy = d2.y; F.dz = d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
@@ -469,8 +471,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
 // acc[pixel] (+)= the batch's samples of that pixel, in sample order (deterministic fp32 sum; raytrace.comp has one
 // sample per frame, the sum over frames is the build's spp extension).
 template <bool CACHE>
-__global__ __launch_bounds__(256) void k_accumulate_paths(const float* __restrict__ plx, const float* __restrict__ ply,
-                                                          const float* __restrict__ plz, const uint32_t* __restrict__ worklist,
+__global__ __launch_bounds__(256) void k_accumulate_paths(const float4* __restrict__ pl, const uint32_t* __restrict__ worklist,
                                                           const uint32_t* __restrict__ wl_count, uint32_t npix_pad,
                                                           uint32_t nsamples, int first_batch, float4* __restrict__ acc) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
@@ -479,19 +480,19 @@ __global__ __launch_bounds__(256) void k_accumulate_paths(const float* __restric
     const uint32_t lp = CACHE ? worklist[w] : w;
     float4 v = first_batch ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : acc[lp];
     for (uint32_t b = 0; b < nsamples; b++) {
-        const size_t r = (size_t)b * nwork + w;
-        v.x = v.x + plx[r]; v.y = v.y + ply[r]; v.z = v.z + plz[r];
+        const float4 l = pl[(size_t)b * nwork + w];
+        v.x = v.x + l.x; v.y = v.y + l.y; v.z = v.z + l.z;
     }
     acc[lp] = v;
 }
 
-hipError_t launch_accumulate_paths(const float* plx, const float* ply, const float* plz, const uint32_t* worklist,
+hipError_t launch_accumulate_paths(const float4* pl, const uint32_t* worklist,
                                    const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool cache,
                                    float4* acc, hipStream_t st) {
     if (npix_pad == 0) return hipSuccess;
     dim3 grid((npix_pad + 255u) / 256u), block(256);
-    if (cache) hipLaunchKernelGGL(k_accumulate_paths<true>, grid, block, 0, st, plx, ply, plz, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, acc);
-    else hipLaunchKernelGGL(k_accumulate_paths<false>, grid, block, 0, st, plx, ply, plz, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, acc);
+    if (cache) hipLaunchKernelGGL(k_accumulate_paths<true>, grid, block, 0, st, pl, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, acc);
+    else hipLaunchKernelGGL(k_accumulate_paths<false>, grid, block, 0, st, pl, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, acc);
     return hipGetLastError();
 }
 

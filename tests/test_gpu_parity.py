@@ -129,3 +129,179 @@ def test_primary_cache_same_pixels(procedural_region, blue_noise, W, H, spp, dep
     assert gcn.rays_primary == W * H
     assert gcn.rays_shadow == ccn.rays_shadow and gcn.rays_diffuse == ccn.rays_diffuse
     assert gcn.rays == ccn.rays - (spp - 1) * W * H
+
+
+@pytest.mark.parametrize("W,H", [(96, 64), (100, 60)])
+def test_tile_split_contexts_reassemble_to_the_full_frame(procedural_region, blue_noise, W, H):
+    """Multi-GPU layout on one GPU: two contexts render the even / odd 8x8 tiles (tile_world = 2), their tile-major
+    planes are concatenated rank-major on the device (what the RCCL gather produces) and rt_untile scatters them;
+    the result must equal the single-context frame (and hence the oracle) on every plane."""
+    import torch
+    mats, mine = procedural_region
+    u = _uniforms(seed=21)
+    spp, depth = 2, 3
+    cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    world_n = 2
+    ctxs = []
+    for r in range(world_n):
+        cfg = render.make_config(W, H, spp=spp, depth=depth, tile_rank=r, tile_world=world_n, flags=abi.RT_FLAG_CACHE_PRIMARY)
+        c = render.Context(cfg)
+        c.upload_world(mats, mine)
+        c.upload_noise(blue_noise)
+        c.draw_frame(u)
+        c.sync()
+        ctxs.append(c)
+    assert sum(c.tile_count() for c in ctxs) == ((W + 7) // 8) * ((H + 7) // 8)
+    assert ctxs[0].tile_capacity() == ctxs[1].tile_capacity()
+    dev = torch.device("cuda", 0)
+    for b in range(abi.RT_BUF_COUNT):
+        nbytes = ctxs[0].buffer_bytes(b)
+        parts = [torch.from_numpy(c.readback(b).reshape(-1).view(np.uint8).copy()).to(dev) for c in ctxs]
+        gathered = torch.cat(parts).contiguous()
+        assert gathered.numel() == world_n * nbytes
+        dt, ch = abi.BUFFER_FORMATS[b]
+        bpp = np.dtype(dt).itemsize * ch
+        frame = torch.zeros(W * H * bpp, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()      # the context runs on its own non-blocking stream
+        ctxs[0].untile(b, gathered.data_ptr(), world_n, frame.data_ptr())
+        ctxs[0].sync()
+        torch.cuda.synchronize()
+        got = frame.cpu().numpy().view(dt).reshape((H, W, ch) if ch > 1 else (H, W))
+        assert np.array_equal(got, cpu[abi.BUFFER_NAMES[b]], equal_nan=True), abi.BUFFER_NAMES[b]
+    for c in ctxs:
+        c.destroy()
+
+
+def test_device_pointer_view_for_collectives(procedural_region, blue_noise):
+    """bench.py hands rt_device_ptr planes to torch.distributed through the CUDA array interface (zero copy)."""
+    import torch
+    import bench
+    mats, mine = procedural_region
+    u = _uniforms(seed=2)
+    cfg = render.make_config(64, 64, spp=1, depth=2)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(u)
+        ctx.sync()
+        b = abi.RT_BUF_FOG_RGBA8
+        view = torch.as_tensor(bench._DevArray(ctx.device_ptr(b), ctx.buffer_bytes(b)), device=torch.device("cuda", 0))
+        assert view.data_ptr() == ctx.device_ptr(b)
+        assert np.array_equal(view.cpu().numpy(), ctx.readback(b).reshape(-1).view(np.uint8))
+
+
+def test_pipeline_mirror_draw_frame(blue_noise):
+    """The C++ mirror of render::create_instance / Pipeline::draw_frame (pipeline.rs:134-255): seed advances per frame
+    ((seed + 1) % 2^20 before the first frame, pipeline.rs:201) and the frame equals the oracle fed the same uniforms."""
+    g = render.Game()
+    g.generate_world(world.DEFAULT_SEED)
+    cfg = render.make_config(64, 48, spp=1, depth=2)
+    p = render.create_instance(cfg, g, blue_noise)
+    mats, mine = world.generate_region(world.DEFAULT_SEED)
+    for frame in range(2):
+        p.draw_frame(g)
+        p.wait()
+        u = p.uniforms()
+        assert u.seed == frame + 1
+        assert tuple(u.lr) == (0, 0, 0)
+        cpu, _ = po.render(mats, mine, blue_noise, u, 64, 48, 1, 2)
+        gpu = p.context.readback_all()
+        for name in cpu:
+            assert np.array_equal(gpu[name], cpu[name], equal_nan=True), name
+    p.close()
+    g.close()
+
+
+def test_upload_slice_matches_full_upload(procedural_region, blue_noise):
+    """rt_upload_slice (terrain_upload.rs:84-275): patching 16-thick slabs on each axis equals uploading the edited region."""
+    mats, mine = procedural_region
+    rng = np.random.default_rng(3)
+    mats2, mine2 = mats.copy(), mine.copy()
+    # carve an empty slab along each axis (minefield 6 / material 0 is a valid "all empty" patch)
+    edits = [(0, 96), (1, 32), (2, 160)]
+    for axis, off in edits:
+        sl = [slice(None)] * 3
+        sl[2 - axis] = slice(off, off + 16)     # arrays are [z, y, x]
+        mats2[tuple(sl)] = 0
+        mine2[tuple(sl)] = 6
+    u = _uniforms(origin=(-20.0, -120.0, 60.0), pitch=-0.3, seed=4)
+    cfg = render.make_config(64, 64, spp=1, depth=2)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        for axis, off in edits:
+            sl = [slice(None)] * 3
+            sl[2 - axis] = slice(off, off + 16)
+            ctx.upload_slice(axis, off, np.ascontiguousarray(mats2[tuple(sl)]), np.ascontiguousarray(mine2[tuple(sl)]))
+        ctx.draw_frame(u)
+        ctx.sync()
+        a = ctx.readback_all()
+        with pytest.raises(render.RtError):
+            ctx.upload_slice(3, 0, np.zeros(16 * 65536, np.uint32), np.zeros(16 * 65536, np.uint8))
+        with pytest.raises(render.RtError):
+            ctx.upload_slice(0, 8, np.zeros(16 * 65536, np.uint32), np.zeros(16 * 65536, np.uint8))
+    cpu, _ = po.render(mats2, mine2, blue_noise, u, 64, 64, 1, 2)
+    for name in cpu:
+        assert np.array_equal(a[name], cpu[name], equal_nan=True), name
+
+
+def test_errors_are_reported_not_fatal(procedural_region, blue_noise):
+    mats, mine = procedural_region
+    cfg = render.make_config(32, 32)
+    with render.Context(cfg) as ctx:
+        with pytest.raises(render.RtError) as e:
+            ctx.draw_frame(_uniforms())
+        assert e.value.code == abi.RT_ERR_NOT_READY
+        bad = mine.copy()
+        bad[10, 10, 10] = 77
+        with pytest.raises(render.RtError) as e:
+            ctx.upload_world(mats, bad)
+        assert e.value.code == abi.RT_ERR_INVALID_ARG and "above 30" in str(e.value)
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(_uniforms())
+        ctx.sync()
+        assert ctx.timing().frame_ms > 0
+
+
+@pytest.mark.parametrize("W,H,spp,depth", [(1920, 1080, 64, 4)])
+def test_full_size_properties(procedural_region, blue_noise, W, H, spp, depth):
+    """BASELINE.json's headline size, checked through size-independent properties instead of the (slow) oracle:
+    - determinism: two frames with the same uniforms are bit-identical;
+    - the primary cache changes no pixel;
+    - planes that depend only on the primary ray equal an spp=1, depth=0 frame;
+    - counters obey the identities fetches = rays + iterations, rays_shadow == rays_diffuse, hits + sky + limit == rays;
+    - a band of rows equals the oracle."""
+    mats, mine = procedural_region
+    u = _uniforms(seed=1)
+
+    def run(spp_, depth_, flags):
+        cfg = render.make_config(W, H, spp=spp_, depth=depth_, flags=flags)
+        with render.Context(cfg) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(u)
+            ctx.sync()
+            first = ctx.readback_all()
+            ctx.draw_frame(u)
+            ctx.sync()
+            second = ctx.readback_all()
+            return first, second, ctx.counters()
+
+    a1, a2, _ = run(spp, depth, abi.RT_FLAG_CACHE_PRIMARY)
+    for name in a1:
+        assert np.array_equal(a1[name], a2[name], equal_nan=True), name
+    b1, _, cn = run(spp, depth, abi.RT_FLAG_COUNTERS)
+    for name in a1:
+        assert np.array_equal(a1[name], b1[name], equal_nan=True), name
+    p1, _, _ = run(1, 0, 0)
+    for name in ("depth_r16", "normal_r8", "albedo_rgba8", "emission_rgba8", "fog_rgba8", "depth_f32", "fog_f32"):
+        assert np.array_equal(a1[name], p1[name], equal_nan=True), name
+    assert cn.frames == 2 and cn.pixels == 2 * W * H
+    assert cn.minefield_fetches == cn.rays + cn.iterations
+    assert cn.rays_shadow == cn.rays_diffuse and cn.rays_primary == 2 * spp * W * H
+    assert cn.hits + cn.sky_exits + cn.limit_exits == cn.rays and cn.material_fetches == cn.hits
+    rows = (536, 544)
+    cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth, rows=rows)
+    for name in cpu:
+        assert np.array_equal(a1[name][rows[0]:rows[1]], cpu[name][rows[0]:rows[1]], equal_nan=True), name
