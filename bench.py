@@ -117,9 +117,23 @@ def main():
     cn = cctx.counters()
     cctx.destroy()
     rays_local = cn.rays
-    # traversal-kernel algorithmic bytes: 1 B per minefield fetch + 4 B per material fetch
+    # traversal algorithmic bytes: 1 B per minefield fetch + 4 B per material fetch
     trace_bytes_local = cn.minefield_fetches + 4 * cn.material_fetches
     balg_local = cn.algorithmic_bytes()
+    ref_equiv_rays_local = cn.rays + (SPP - 1) * cn.pixels if args.cache_primary else cn.rays
+    if args.kernel == "persistent" and args.cache_primary and D >= 1:
+        # the dominant kernel (k_persist) walks only shadow/diffuse rays; the primary prepass (k_primary) is a separate,
+        # untimed-for-roofline launch: subtract its share, measured with a depth-0 counting frame
+        cfg0 = render.make_config(W, H, spp=SPP, depth=0, device=local_rank, tile_rank=rank, tile_world=world,
+                                  kernel=kernel, flags=abi.RT_FLAG_COUNTERS | xflags)
+        c0 = render.Context(cfg0)
+        c0.upload_world(mats, mine)
+        c0.upload_noise(noise)
+        c0.draw_frame(u)
+        c0.sync()
+        cn0 = c0.counters()
+        c0.destroy()
+        trace_bytes_local -= cn0.minefield_fetches + 4 * cn0.material_fetches
 
     ctx = make_ctx(abi.RT_FLAG_TIMING)
     stream = torch.cuda.current_stream(dev)
@@ -166,12 +180,13 @@ def main():
     elapsed = time.perf_counter() - t0
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    sums = torch.tensor([float(rays_local), float(trace_bytes_local), float(balg_local)], dtype=torch.float64, device=dev)
+    sums = torch.tensor([float(rays_local), float(trace_bytes_local), float(balg_local), float(ref_equiv_rays_local)],
+                        dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     elapsed = float(t_all.item())
-    rays_total, trace_bytes_total, balg_total = [float(x) for x in sums.tolist()]
+    rays_total, trace_bytes_total, balg_total, ref_rays_total = [float(x) for x in sums.tolist()]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -182,7 +197,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_r1.json")
         if os.path.exists(tpath) and (W, H, SPP, D) == (1920, 1080, 64, 4) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get("k_trace_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k_%s_hbm_bytes_per_launch" % {"persistent": "persist", "wavefront": "trace", "mega": "mega"}[args.kernel])
             except Exception:
                 traffic = None
         out = {
@@ -191,7 +206,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d spp=%d depth=%d, procedural 256^3 region seed 0x5EED, pose (-30,-128,100) h=pi/2 p=0 sun=0"
-                                   % (W, H, SPP, D), "kernel": args.kernel, "rays_per_frame": int(rays_total),
+                                   % (W, H, SPP, D), "kernel": args.kernel, "rays_per_frame": int(rays_total), "reference_equivalent_rays_per_frame": int(ref_rays_total),
                        "algorithmic_bytes_per_frame": int(balg_total), "parallelism": "tiles%d" % world,
                        "primary_cache": bool(args.cache_primary)},
             "roofline": {"bound": "hbm", "kernel": {"persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}[args.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -465,6 +465,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         if (e == hipSuccess && ctx->cfg.depth >= 1) {
             LaunchTimer t(ctx, 1);
             e = rtd::launch_sun_lut(f, ctx->sun_lut, ctx->stream);
+            if (e == hipSuccess) e = rtd::launch_sky_lut(f, ctx->dif_lut, ctx->stream);
         }
         if (!cache || ctx->cfg.depth >= 1) {
             const uint32_t spp = (uint32_t)ctx->cfg.spp, B = ctx->persist_batch;
@@ -555,6 +556,11 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     out->noise_fetches = d.noise_fetches + ctx->host_noise_base;   // + the seed-base texel of each sample (raytrace.comp:302-303)
     out->hits = d.hits; out->sky_exits = d.sky_exits; out->limit_exits = d.limit_exits; out->border_fetches = d.border_fetches;
     out->pixels = d.pixels; out->frames = ctx->host_frames;
+    if (getenv("RT_DEBUG_STATS"))
+        fprintf(stderr, "[rt] wave loop iters %llu | S block execs %llu (avg lanes %.1f) | F block execs %llu (avg lanes %.1f) | passes %llu "
+                        "(avg lanes %.1f, sky lanes %.1f)\n", d.dbg_loop_iters, d.dbg_s_execs, d.dbg_s_execs ? (double)d.dbg_s_lanes / d.dbg_s_execs : 0.0,
+                d.dbg_f_execs, d.dbg_f_execs ? (double)d.dbg_f_lanes / d.dbg_f_execs : 0.0, d.dbg_passes,
+                d.dbg_passes ? (double)d.dbg_pass_lanes / d.dbg_passes : 0.0, d.dbg_passes ? (double)d.dbg_sky_lanes / d.dbg_passes : 0.0);
     return RT_OK;
 }
 

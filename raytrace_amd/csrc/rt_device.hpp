@@ -305,6 +305,8 @@ __device__ __forceinline__ vec3 unwind_light(int K, uint32_t sunbits, bool termi
 struct DevCounters {
     unsigned long long rays, rays_primary, rays_shadow, rays_diffuse, iterations, minefield_fetches,
         material_fetches, noise_fetches, hits, sky_exits, limit_exits, border_fetches, pixels, frames;
+    // kernel-structure statistics of counting builds (not part of RtCounters; RT_DEBUG_STATS=1 prints them)
+    unsigned long long dbg_loop_iters, dbg_s_execs, dbg_f_execs, dbg_s_lanes, dbg_f_lanes, dbg_passes, dbg_pass_lanes, dbg_sky_lanes;
 };
 // Sum `v` over the wave and let one lane add it.
 __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {

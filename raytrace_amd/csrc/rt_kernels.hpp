@@ -68,7 +68,7 @@ struct PersistArgs {
     const float *phx, *phy, *phz;   // CACHE: primary hit per local pixel
     const uint32_t* pinfo;
     const float4* sun_lut;      // [2*65536] per-frame shadow-ray table: direction, 1/|direction|
-    const float4* dif_lut;      // [4*6*65536] diffuse-ray table, one 64-byte line per (face, noise byte pair): dir, normalized dir, 1/|dir|, pad
+    const float4* dif_lut;      // [4*6*65536] diffuse-ray table, one 64-byte line per (face, noise byte pair): dir, normalized dir, 1/|dir|, per-frame sky(dir)
     float4* pl;                 // [nsamples * nwork] light of each path (one 16-byte store per path)
     DevCounters* counters;
 };
@@ -78,6 +78,7 @@ hipError_t launch_accumulate_paths(const float4* pl, const uint32_t* worklist,
 hipError_t launch_sphere_lut(float4* lut, hipStream_t st);
 hipError_t launch_dif_lut(const float4* sphere, float4* lut, hipStream_t st);
 hipError_t launch_sun_lut(const Frame& f, float4* lut, hipStream_t st);
+hipError_t launch_sky_lut(const Frame& f, float4* dif_lut, hipStream_t st);
 hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count, hipStream_t st);
 hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
                           int nworkgroups, hipStream_t st);

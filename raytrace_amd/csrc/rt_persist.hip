@@ -158,6 +158,16 @@ struct RaySlot {
     bool tracing, valid, fresh, fresh_invalid;
 };
 
+// sample_sky(diffuse_direction, ..., true) (raytrace.comp:331-332 / :343-345) for every entry of the diffuse table, written
+// once per frame into the entry's fourth slot: a path that ends on a sky exit reads its sky light instead of
+// evaluating three pow() per lane in the transition pass.
+__global__ __launch_bounds__(256) void k_build_sky_lut(Frame f, float4* __restrict__ dif_lut) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly 6 * 65536
+    const float4 dd = dif_lut[4 * i];
+    const vec3 sky = sample_sky(v3(dd.x, dd.y, dd.z), ld3(f.sunangle), ld3(f.sunlight), true);
+    dif_lut[4 * i + 3] = make_float4(sky.x, sky.y, sky.z, 0.0f);
+}
+
 template <bool LRZ, bool COUNT, bool CACHE>
 __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes pl, PersistArgs a) {
     __shared__ uint32_t s_coarse[kCoarseWords];
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     // ---- path state ----
     uint32_t phase = PH_EMPTY;                // PH_EMPTY, PH_PRIMARY (F only, CACHE=false), PH_DIF (= a level: S and F)
     uint32_t item = 0, lp = 0, samp = 0, level = 0, sunbits = 0;
-    float ddx = 0, ddy = 0, ddz = 0;          // diffuse direction in flight (sample_sky argument)
+    uint32_t dif_entry = 0;                   // diffuse-table entry of the level in flight (its slot 3 = sample_sky of that direction)
     uint32_t nvtex = 0;                       // noise_value texel of the path (raytrace.comp:324,336)
     bool exhausted = false;
     constexpr uint32_t kChunk = 512;
@@ -198,6 +208,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
 
     unsigned long long c_prim = 0, c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0,
                        c_noise = 0, c_pix = 0;
+    unsigned long long d_iters = 0, d_sx = 0, d_fx = 0, d_sl = 0, d_fl = 0, d_pass = 0, d_pl = 0, d_sky = 0;   // wave-uniform
 
     // ---- head of trace_ray (:83-107) ---------------------------------------------------------------------------
     // origin part, shared by the two rays of a level (same surface point): texel of the first fetch (:106, Q6)
@@ -294,6 +305,10 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 if (gF) byF = sc.mine[F.vox];
                 if (gS) stS = byS;
                 if (gF) stF = byF;
+                if (COUNT) {
+                    const uint32_t nS = (uint32_t)__popcll(__ballot(S.tracing)), nF = (uint32_t)__popcll(__ballot(F.tracing));
+                    d_iters++; if (nS) { d_sx++; d_sl += nS; } if (nF) { d_fx++; d_fl += nF; }
+                }
                 if (S.tracing) advance(S, stS);
                 if (F.tracing) advance(F, stF);
             } while ((uint32_t)__popcll(__ballot(S.tracing || F.tracing)) > target);
@@ -303,6 +318,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
 
         // =========================== transition pass ===========================================================
         const bool mine = !(S.tracing || F.tracing) && phase != PH_EMPTY;
+        if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); d_sky += (uint32_t)__popcll(__ballot(mine && phase == PH_DIF && F.kind == PX_AIR)); }
         bool path_done = false, begin_level = false, need_primary = false;
         vec3 light = v3(0, 0, 0);
         float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 if (S.kind == PX_AIR) sunbits |= 1u << (level - 1);
                 if (air || level == D) {
                     vec3 sky = v3(0, 0, 0);
-                    if (air) sky = sample_sky(v3(ddx, ddy, ddz), sunangle, sunlight, true);        // :331-332 / :343-345
+                    if (air) { const float4 t = a.dif_lut[dif_entry + 3u]; sky = v3(t.x, t.y, t.z); }   // :331-332 / :343-345, tabulated
                     // L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
                     vec3 L = v3(0.0f, 0.0f, 0.0f);
                     if (sunbits >> (level - 1) & 1u) L = vadd(L, sunlight);
@@ -438,8 +454,8 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             S.dx = sd.x; S.dy = sd.y; S.dz = sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
             arm(S, ro, ok, vox0);
             const uint32_t di = 4u * ((snormal << 16) | (nvtex & 0xFFFFu));
-            const float4 dd = a.dif_lut[di], d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
-            ddx = dd.x; ddy = dd.y; ddz = dd.z;
+            const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
+            dif_entry = di;
             F.dx = d2.x; F.dy = d2.y; F.dz = d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
             arm(F, ro, ok, vox0);
             phase = PH_DIF;
@@ -465,6 +481,11 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
         wave_add(&cn->hits, c_hits); wave_add(&cn->material_fetches, c_hits); wave_add(&cn->sky_exits, c_sky);
         wave_add(&cn->limit_exits, c_limit); wave_add(&cn->border_fetches, c_border); wave_add(&cn->noise_fetches, c_noise);
         wave_add(&cn->pixels, c_pix);
+        if (lane == 0) {
+            atomicAdd(&cn->dbg_loop_iters, d_iters); atomicAdd(&cn->dbg_s_execs, d_sx); atomicAdd(&cn->dbg_f_execs, d_fx);
+            atomicAdd(&cn->dbg_s_lanes, d_sl); atomicAdd(&cn->dbg_f_lanes, d_fl); atomicAdd(&cn->dbg_passes, d_pass);
+            atomicAdd(&cn->dbg_pass_lanes, d_pl); atomicAdd(&cn->dbg_sky_lanes, d_sky);
+        }
     }
 }
 
@@ -498,6 +519,11 @@ hipError_t launch_accumulate_paths(const float4* pl, const uint32_t* worklist,
 
 hipError_t launch_sun_lut(const Frame& f, float4* lut, hipStream_t st) {
     hipLaunchKernelGGL(k_build_sun_lut, dim3(65536 / 256), dim3(256), 0, st, f, lut);
+    return hipGetLastError();
+}
+
+hipError_t launch_sky_lut(const Frame& f, float4* dif_lut, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_sky_lut, dim3(6 * 65536 / 256), dim3(256), 0, st, f, dif_lut);
     return hipGetLastError();
 }
 
