@@ -140,7 +140,9 @@ typedef enum RtBufferId {
     RT_BUF_LIGHTING_F32    = 6, /* the vec4 handed to imageStore before UNORM conversion      16 B/px */
     RT_BUF_FOG_F32         = 7, /* same for fog                                               16 B/px */
     RT_BUF_DEPTH_F32       = 8, /* |origin-pos|*32 before uint(); 65535.0 for sky             4 B/px */
-    RT_BUF_COUNT           = 9
+    RT_BUF_FINAL_BGRA8     = 9, /* rt_finalize output = the swapchain image (finalize.comp:62): B8G8R8A8_UNORM
+                                   (core_builder.rs:557-568), rows TOP-down (the shader flips Y)   4 B/px */
+    RT_BUF_COUNT           = 10
 } RtBufferId;
 
 /* Exact integer counters (RT_FLAG_COUNTERS), accumulated since the last rt_reset_counters.
@@ -228,6 +230,17 @@ int rt_tile_capacity(RtContext* ctx);
 /* Scatter `world` gathered tile-major planes (rank-major: world x capacity x 64 px x bpp, device
  * memory) into a row-major full-frame plane (device memory) on this context's stream. */
 int rt_untile(RtContext* ctx, int buffer_id, const void* gathered_dev, int world, void* frame_dev);
+
+/* The six bilateral_denoise.comp dispatches recorded at pipeline.rs:98-115 (sizes 1,2,4,8,8,16, ping/pong descriptor
+ * sets): filters RT_BUF_LIGHTING_RGBA16 in place using the depth and normal planes.  faithful != 0 reproduces the
+ * reference's pong descriptor set, which binds the normal and depth images swapped (descriptor_sets.rs:38-39 vs :31-32), so
+ * passes 2, 4 and 6 only filter pixels whose DEPTH value is below 16; faithful == 0 binds them consistently.
+ * Whole-frame contexts only (tile_world == 1): a 3*16-pixel halo is needed, so gather first. Asynchronous. */
+int rt_denoise(RtContext* ctx, int faithful);
+
+/* finalize.comp (pipeline.rs:117-123): albedo*light*16 + emission*4, distance fog, tone curve, blue-noise dither, Y flip
+ * -> RT_BUF_FINAL_BGRA8.  Whole-frame contexts only. Asynchronous. */
+int rt_finalize(RtContext* ctx);
 
 int rt_get_counters(RtContext* ctx, RtCounters* out);
 int rt_reset_counters(RtContext* ctx);

@@ -173,3 +173,29 @@ def f2u16(x):
     f.restype = C.c_uint32
     f.argtypes = [C.c_float]
     return int(f(float(x)))
+
+
+def denoise(lighting_rgba16, depth_r16, normal_r8, faithful=True):
+    """The six bilateral_denoise.comp dispatches (pipeline.rs:98-115) on [H,W,4] uint16 lighting; returns the result."""
+    lighting = np.ascontiguousarray(lighting_rgba16, dtype=np.uint16).copy()
+    depth = np.ascontiguousarray(depth_r16, dtype=np.uint16)
+    normal = np.ascontiguousarray(normal_r8, dtype=np.uint8)
+    h, w = depth.shape
+    rc = lib().rt_oracle_denoise(_p(lighting), _p(depth), _p(normal), C.c_int(w), C.c_int(h), C.c_int(1 if faithful else 0))
+    assert rc == 0
+    return lighting
+
+
+def finalize(albedo_rgba8, emission_rgba8, fog_rgba8, lighting_rgba16, depth_r16, noise):
+    """finalize.comp -> [H,W,4] uint8 in B,G,R,A byte order, rows top-down."""
+    a = np.ascontiguousarray(albedo_rgba8, dtype=np.uint8)
+    e = np.ascontiguousarray(emission_rgba8, dtype=np.uint8)
+    f = np.ascontiguousarray(fog_rgba8, dtype=np.uint8)
+    l = np.ascontiguousarray(lighting_rgba16, dtype=np.uint16)
+    d = np.ascontiguousarray(depth_r16, dtype=np.uint16)
+    n = np.ascontiguousarray(noise, dtype=np.uint8).reshape(-1)
+    h, w = d.shape
+    out = np.zeros((h, w, 4), dtype=np.uint8)
+    rc = lib().rt_oracle_finalize(_p(a), _p(e), _p(f), _p(l), _p(d), _p(n), C.c_int(w), C.c_int(h), _p(out))
+    assert rc == 0
+    return out

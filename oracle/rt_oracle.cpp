@@ -443,6 +443,133 @@ int rt_oracle_render(const uint32_t* materials, const uint8_t* minefield, const 
 void rt_oracle_fetch_stats_begin(const uint8_t* uniform4) { g_uniform4 = uniform4; memset(g_fetch_hist, 0, sizeof(g_fetch_hist)); }
 void rt_oracle_fetch_stats_end(uint64_t* out64) { memcpy(out64, g_fetch_hist, sizeof(g_fetch_hist)); g_uniform4 = nullptr; }
 
+}  // extern "C"
+
+// =====================================================================================================
+// bilateral_denoise.comp and finalize.comp — restated for the parity tests of the
+// post-passes.  Images are UNORM / UINT storage images: imageLoad returns u16/65535, u8/255 or the integer.
+// =====================================================================================================
+namespace {
+struct Tap { int dx, dy; float w; };
+// the 36 SAMPLE(...) lines of bilateral_denoise.comp:45-88, in source order
+const Tap kTaps[36] = {
+    {0, 1, 0.092566f}, {0, -1, 0.092566f}, {1, 0, 0.092566f}, {-1, 0, 0.092566f},
+    {1, 1, 0.058434f}, {-1, 1, 0.058434f}, {-1, -1, 0.058434f}, {1, -1, 0.058434f},
+    {2, 0, 0.023205f}, {-2, 0, 0.023205f}, {0, 2, 0.023205f}, {0, -2, 0.023205f},
+    {2, 2, 0.003672f}, {-2, 2, 0.003672f}, {-2, -2, 0.003672f}, {2, -2, 0.003672f},
+    {2, 1, 0.014648f}, {-2, 1, 0.014648f}, {-2, -1, 0.014648f}, {2, -1, 0.014648f},
+    {1, 2, 0.014648f}, {-1, 2, 0.014648f}, {-1, -2, 0.014648f}, {1, -2, 0.014648f},
+    {3, 0, 0.002289f}, {-3, 0, 0.002289f}, {0, 3, 0.002289f}, {0, -3, 0.002289f},
+    {3, 1, 0.001445f}, {-3, 1, 0.001445f}, {-3, -1, 0.001445f}, {3, -1, 0.001445f},
+    {1, 3, 0.001445f}, {-1, 3, 0.001445f}, {-1, -3, 0.001445f}, {1, -3, 0.001445f}};
+
+// One dispatch of bilateral_denoise.comp.  `depth_img` / `normal_img` are what the shader's bindings 1 and 2 return:
+// on the "pong" descriptor set the reference binds them SWAPPED (descriptor_sets.rs:38-39 vs :31-32), so binding 1
+// (declared r16ui) reads the normal image and binding 2 (declared r8ui) reads the depth image; the loads are taken
+// to return the bound image's own integer value.
+void denoise_pass(const uint16_t* lin, const uint32_t* depth_img, const uint32_t* normal_img, int W, int H, int size,
+                  uint16_t* lout) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t c = (size_t)y * W + x;
+            float center_distance = (float)depth_img[c] / 256.0f;                                  // :36
+            uint32_t center_normal = normal_img[c];                                                // :37
+            if (center_normal < 16) {                                                              // :39
+                float total_weight = 0.146634f;                                                    // :40
+                float sum[3];
+                for (int k = 0; k < 3; k++) sum[k] = ((float)lin[c * 4 + k] / 65535.0f) * total_weight;   // :41
+                for (const Tap& t : kTaps) {                                                       // SAMPLE, :23-33
+                    int px = x + t.dx * size, py = y + t.dy * size;                                // sampleAt, :14-21
+                    if (px < 0) px = 0;
+                    if (py < 0) py = 0;
+                    if (px >= W) px = W - 1;
+                    if (py >= H) py = H - 1;
+                    const size_t i = (size_t)py * W + px;
+                    float dist = (float)depth_img[i] / 256.0f;
+                    float distance_difference = 4.0f * rtm_abs(center_distance - dist);
+                    float normal_difference = normal_img[i] == center_normal ? 0.0f : 10.0f;
+                    float weight = t.w / (distance_difference + normal_difference + 1.0f);
+                    total_weight += weight;
+                    for (int k = 0; k < 3; k++) sum[k] = rtm_fma((float)lin[i * 4 + k] / 65535.0f, weight, sum[k]);
+                }
+                for (int k = 0; k < 3; k++) lout[c * 4 + k] = (uint16_t)rtm_unorm(sum[k] / total_weight, 65535.0f);   // :89
+                lout[c * 4 + 3] = 65535;
+            } else {
+                for (int k = 0; k < 4; k++) lout[c * 4 + k] = lin[c * 4 + k];                      // :91
+            }
+        }
+}
+
+// filmic_curve — finalize.comp:21-31
+inline float filmic_curve(float x) {
+    if (x < 0.3f) return x * x;
+    if (x < 1.13333f) return rtm_fma(x, 0.6f, -0.09f);
+    if (x < 2.5f) return rtm_fma(-0.219512195116f * (x - 2.5f), x - 2.5f, 1.0f);
+    return 1.0f;
+}
+}  // namespace
+
+extern "C" {
+// The six denoise dispatches of pipeline.rs:98-115 (sizes 1,2,4,8,8,16; ping / pong descriptor sets alternate).
+// lighting is updated in place (the sixth pass writes lighting_buffer).  faithful != 0 reproduces the swapped
+// bindings of the pong set; faithful == 0 binds depth and normal the same way in every pass.
+int rt_oracle_denoise(uint16_t* lighting_rgba16, const uint16_t* depth_r16, const uint8_t* normal_r8, int W, int H, int faithful) {
+    const size_t n = (size_t)W * H;
+    std::vector<uint32_t> depth(n), normal(n);
+    for (size_t i = 0; i < n; i++) { depth[i] = depth_r16[i]; normal[i] = normal_r8[i]; }
+    std::vector<uint16_t> pong(n * 4);
+    const int sizes[6] = {1, 2, 4, 8, 8, 16};
+    for (int pass = 0; pass < 6; pass++) {
+        const bool odd = pass % 2 == 1;
+        const uint16_t* in = odd ? pong.data() : lighting_rgba16;
+        uint16_t* out = odd ? lighting_rgba16 : pong.data();
+        const bool swapped = odd && faithful;
+        denoise_pass(in, swapped ? normal.data() : depth.data(), swapped ? depth.data() : normal.data(), W, H, sizes[pass], out);
+    }
+    return RT_OK;
+}
+
+// finalize.comp:33-63.  Output is the swapchain image: B8G8R8A8_UNORM (core_builder.rs:557-568), rows top-down
+// (the shader flips Y, :60-62).
+int rt_oracle_finalize(const uint8_t* albedo_rgba8, const uint8_t* emission_rgba8, const uint8_t* fog_rgba8,
+                       const uint16_t* lighting_rgba16, const uint16_t* depth_r16, const uint8_t* noise, int W, int H,
+                       uint8_t* out_bgra8) {
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t c = (size_t)y * W + x;
+            float final_color[3];
+            for (int k = 0; k < 3; k++) {
+                float albedo = (float)albedo_rgba8[c * 4 + k] / 255.0f;
+                float emission = ((float)emission_rgba8[c * 4 + k] / 255.0f) * 4.0f;                   // :37
+                float light = ((float)lighting_rgba16[c * 4 + k] / 65535.0f) * RT_LIGHTING_SCALE;       // :39
+                final_color[k] = rtm_fma(albedo, light, emission);                                      // :40
+            }
+            uint32_t depth = depth_r16[c];
+            if (depth < 0xFFFFu) {                                                                      // :44-49
+                float fog_amount = (float)depth / (32.0f * 128.0f * 8.0f);
+                if (fog_amount > 1.0f) fog_amount = 1.0f;
+                for (int k = 0; k < 3; k++) {
+                    float fog = ((float)fog_rgba8[c * 4 + k] / 255.0f) * 2.0f;
+                    final_color[k] = rtm_mix(final_color[k], fog, fog_amount);
+                }
+            }
+            const uint8_t* nt = noise + ((size_t)(y % RT_NOISE_SIZE) * RT_NOISE_SIZE + (x % RT_NOISE_SIZE)) * 4;   // :55-57
+            uint8_t rgb[3];
+            for (int k = 0; k < 3; k++) {
+                float v = filmic_curve(final_color[k]) + ((float)nt[k] / 255.0f) / 128.0f;              // :51-58
+                rgb[k] = (uint8_t)rtm_unorm(v, 255.0f);
+            }
+            uint8_t* o = out_bgra8 + ((size_t)(H - y - 1) * W + x) * 4;                                 // :60-62
+            o[0] = rgb[2]; o[1] = rgb[1]; o[2] = rgb[0]; o[3] = 255;
+        }
+    return RT_OK;
+}
+}  // extern "C"
+
+extern "C" {
 // ---- arithmetic-contract probes (tests/test_math_contract.py): fn 0 sin, 1 cos, 2 acos, 3 pow(x,y), 4 mod(x,y),
 // 5 exp2, 6 log2, 7 sqrt, 8 1/x ----
 void rt_oracle_math(int fn, const float* x, const float* y, float* out, size_t n) {

@@ -26,7 +26,7 @@ RT_FLAG_TIMING = 0x4
 
 (RT_BUF_LIGHTING_RGBA16, RT_BUF_DEPTH_R16UI, RT_BUF_NORMAL_R8UI, RT_BUF_ALBEDO_RGBA8,
  RT_BUF_EMISSION_RGBA8, RT_BUF_FOG_RGBA8, RT_BUF_LIGHTING_F32, RT_BUF_FOG_F32,
- RT_BUF_DEPTH_F32, RT_BUF_COUNT) = range(10)
+ RT_BUF_DEPTH_F32, RT_BUF_FINAL_BGRA8, RT_BUF_COUNT) = range(11)
 
 # (numpy dtype, channels) per output plane
 BUFFER_FORMATS = {
@@ -39,11 +39,13 @@ BUFFER_FORMATS = {
     RT_BUF_LIGHTING_F32: ("float32", 4),
     RT_BUF_FOG_F32: ("float32", 4),
     RT_BUF_DEPTH_F32: ("float32", 1),
+    RT_BUF_FINAL_BGRA8: ("uint8", 4),
 }
 BUFFER_NAMES = {
     RT_BUF_LIGHTING_RGBA16: "lighting_rgba16", RT_BUF_DEPTH_R16UI: "depth_r16", RT_BUF_NORMAL_R8UI: "normal_r8",
     RT_BUF_ALBEDO_RGBA8: "albedo_rgba8", RT_BUF_EMISSION_RGBA8: "emission_rgba8", RT_BUF_FOG_RGBA8: "fog_rgba8",
     RT_BUF_LIGHTING_F32: "lighting_f32", RT_BUF_FOG_F32: "fog_f32", RT_BUF_DEPTH_F32: "depth_f32",
+    RT_BUF_FINAL_BGRA8: "final_bgra8",
 }
 
 

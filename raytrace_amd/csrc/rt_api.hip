@@ -22,7 +22,7 @@ thread_local std::string g_create_error = "";
 constexpr int kR = RT_ROOT_BLOCK_SIZE;
 constexpr size_t kVox = (size_t)kR * kR * kR;
 
-const size_t kBytesPerPixel[RT_BUF_COUNT] = {8, 2, 1, 4, 4, 4, 16, 16, 4};
+const size_t kBytesPerPixel[RT_BUF_COUNT] = {8, 2, 1, 4, 4, 4, 16, 16, 4, 4};
 
 }  // namespace
 
@@ -45,6 +45,7 @@ struct RtContext {
     size_t plane_pixels = 0;   // pixels per output plane
 
     void* planes[RT_BUF_COUNT] = {};
+    void* lighting_pong = nullptr;   // lighting_pong_buffer, render_data.rs:178-182
 
     // wavefront pipeline state
     int kernel = RT_KERNEL_PERSISTENT;
@@ -308,6 +309,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         c->planes[b] = p;
     }
 
+    { uint8_t* p = nullptr; RT_HIP_CREATE(dev_alloc(c, &p, c->plane_pixels * 8)); c->lighting_pong = p; }
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD_SUN")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold_sun = (uint32_t)v; }
@@ -542,6 +544,35 @@ int rt_untile(RtContext* ctx, int id, const void* gathered_dev, int world, void*
     const int capacity = (ctx->ntiles_total + world - 1) / world;
     RT_HIP(ctx, rtd::launch_untile(gathered_dev, frame_dev, world, capacity, ctx->tiles_x, ctx->tiles_y, ctx->cfg.width,
                                    ctx->cfg.height, (int)kBytesPerPixel[id], ctx->stream));
+    return RT_OK;
+}
+
+int rt_denoise(RtContext* ctx, int faithful) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->cfg.tile_world != 1) return fail(ctx, RT_ERR_UNIMPLEMENTED, "rt_denoise: whole-frame contexts only (gather the tiles first)");
+    if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_denoise: no frame drawn yet");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int sizes[6] = {1, 2, 4, 8, 8, 16};                         // pipeline.rs:103
+    void* ping = ctx->planes[RT_BUF_LIGHTING_RGBA16];
+    void* pong = ctx->lighting_pong;
+    for (int pass = 0; pass < 6; pass++) {
+        const bool odd = pass % 2 == 1;                               // pipeline.rs:104-108: ping set on even, pong set on odd
+        LaunchTimer t(ctx, 1);
+        RT_HIP(ctx, rtd::launch_denoise(odd ? pong : ping, ctx->planes[RT_BUF_DEPTH_R16UI], ctx->planes[RT_BUF_NORMAL_R8UI],
+                                        ctx->cfg.width, ctx->cfg.height, sizes[pass], odd && faithful != 0, odd ? ping : pong, ctx->stream));
+    }
+    return RT_OK;
+}
+
+int rt_finalize(RtContext* ctx) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->cfg.tile_world != 1) return fail(ctx, RT_ERR_UNIMPLEMENTED, "rt_finalize: whole-frame contexts only (gather the tiles first)");
+    if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_finalize: no frame drawn yet");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    LaunchTimer t(ctx, 1);
+    RT_HIP(ctx, rtd::launch_finalize(ctx->planes[RT_BUF_ALBEDO_RGBA8], ctx->planes[RT_BUF_EMISSION_RGBA8], ctx->planes[RT_BUF_FOG_RGBA8],
+                                     ctx->planes[RT_BUF_LIGHTING_RGBA16], ctx->planes[RT_BUF_DEPTH_R16UI], ctx->d_noise, ctx->cfg.width,
+                                     ctx->cfg.height, ctx->planes[RT_BUF_FINAL_BGRA8], ctx->stream));
     return RT_OK;
 }
 

@@ -13,7 +13,7 @@ import math
 import numpy as np
 
 from . import _lib
-from .abi import (BUFFER_FORMATS, BUFFER_NAMES, RT_BUF_COUNT, RT_KERNEL_DEFAULT, RtConfig, RtCounters, RtTiming,
+from .abi import (BUFFER_FORMATS, BUFFER_NAMES, RT_BUF_COUNT, RT_BUF_FINAL_BGRA8, RT_KERNEL_DEFAULT, RtConfig, RtCounters, RtTiming,
                   RtUniforms)
 
 
@@ -136,11 +136,19 @@ class Context:
         return out.reshape(shape)
 
     def readback_all(self):
-        return {BUFFER_NAMES[b]: self.readback(b) for b in range(RT_BUF_COUNT)}
+        """The nine planes the ray-trace dispatch writes (not the finalize output)."""
+        return {BUFFER_NAMES[b]: self.readback(b) for b in range(RT_BUF_FINAL_BGRA8)}
 
     def untile(self, buffer_id, gathered_dev_ptr, world, frame_dev_ptr):
         self._check(self._lib.rt_untile(self._h, int(buffer_id), C.c_void_p(gathered_dev_ptr), int(world),
                                         C.c_void_p(frame_dev_ptr)))
+
+    # -- post passes (pipeline.rs:98-123) ----------------------------------------------------------------
+    def denoise(self, faithful=True):
+        self._check(self._lib.rt_denoise(self._h, 1 if faithful else 0))
+
+    def finalize(self):
+        self._check(self._lib.rt_finalize(self._h))
 
     # -- instrumentation ---------------------------------------------------------------------------------
     def counters(self):

@@ -21,7 +21,7 @@ def _declared_functions():
 def test_library_exports_every_declared_symbol():
     lib = _lib.amd()
     declared = _declared_functions()
-    assert len(declared) >= 19
+    assert len(declared) >= 21
     assert sorted(_lib.ABI_SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name), "librt_amd.so does not export %s" % name
@@ -44,7 +44,7 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(abi.RtCounters) == 8 * 14
     assert len(re.findall(r"uint64_t\s+\w+;", text.split("typedef struct RtCounters")[1].split("}")[0])) == 14
     assert C.sizeof(abi.RtTiming) == 32
-    for name in ("RT_BUF_LIGHTING_RGBA16 = 0", "RT_BUF_DEPTH_F32       = 8", "RT_BUF_COUNT           = 9"):
+    for name in ("RT_BUF_LIGHTING_RGBA16 = 0", "RT_BUF_DEPTH_F32       = 8", "RT_BUF_FINAL_BGRA8     = 9", "RT_BUF_COUNT           = 10"):
         assert name in text
 
 

@@ -154,7 +154,7 @@ def test_tile_split_contexts_reassemble_to_the_full_frame(procedural_region, blu
     assert sum(c.tile_count() for c in ctxs) == ((W + 7) // 8) * ((H + 7) // 8)
     assert ctxs[0].tile_capacity() == ctxs[1].tile_capacity()
     dev = torch.device("cuda", 0)
-    for b in range(abi.RT_BUF_COUNT):
+    for b in range(abi.RT_BUF_FINAL_BGRA8):
         nbytes = ctxs[0].buffer_bytes(b)
         parts = [torch.from_numpy(c.readback(b).reshape(-1).view(np.uint8).copy()).to(dev) for c in ctxs]
         gathered = torch.cat(parts).contiguous()
