@@ -87,9 +87,17 @@ def main():
 
     if rank == 0:
         build.build()
+    # RT_BENCH_BACKEND=gloo + RT_BENCH_SINGLE_DEVICE=1 rehearse the N>1 path on a one-GPU box (every rank on GPU 0, planes
+    # staged through host memory for the gather); the real run uses RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if os.environ.get("RT_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
         dist.barrier()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -153,11 +161,21 @@ def main():
         ctx.draw_frame(u)
         if world > 1:
             for b in gather_ids:
+                if backend == "nccl":
+                    if rank == 0:
+                        dist.gather(local_views[b], list(gathered[b].chunk(world)), dst=0)
+                    else:
+                        dist.gather(local_views[b], None, dst=0)
+                else:   # rehearsal backend: stage through host memory
+                    host = local_views[b].cpu()
+                    if rank == 0:
+                        parts = [torch.empty_like(host) for _ in range(world)]
+                        dist.gather(host, parts, dst=0)
+                        gathered[b].copy_(torch.cat(parts))
+                    else:
+                        dist.gather(host, None, dst=0)
                 if rank == 0:
-                    dist.gather(local_views[b], list(gathered[b].chunk(world)), dst=0)
                     ctx.untile(b, gathered[b].data_ptr(), world, frames[b].data_ptr())
-                else:
-                    dist.gather(local_views[b], None, dst=0)
 
     def fence():
         if world > 1:
@@ -188,6 +206,17 @@ def main():
     elapsed = float(t_all.item())
     rays_total, trace_bytes_total, balg_total, ref_rays_total = [float(x) for x in sums.tolist()]
 
+    # content hash of the finished frame on rank 0 (outside the timed region): equal for every N
+    frame_sha = None
+    if rank == 0:
+        import hashlib
+        hsh = hashlib.sha256()
+        for b in gather_ids:
+            if world > 1:
+                hsh.update(frames[b].cpu().numpy().tobytes())
+            else:
+                hsh.update(ctx.readback(b).tobytes())
+        frame_sha = hsh.hexdigest()[:16]
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays_total * args.steps / elapsed / 1e6
@@ -208,7 +237,7 @@ def main():
             "config": {"workload": "%dx%d spp=%d depth=%d, procedural 256^3 region seed 0x5EED, pose (-30,-128,100) h=pi/2 p=0 sun=0"
                                    % (W, H, SPP, D), "kernel": args.kernel, "rays_per_frame": int(rays_total), "reference_equivalent_rays_per_frame": int(ref_rays_total),
                        "algorithmic_bytes_per_frame": int(balg_total), "parallelism": "tiles%d" % world,
-                       "primary_cache": bool(args.cache_primary)},
+                       "primary_cache": bool(args.cache_primary), "frame_sha256_16": frame_sha},
             "roofline": {"bound": "hbm", "kernel": {"persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}[args.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launches_per_frame": trace_launches // max(args.steps, 1),

@@ -4,6 +4,8 @@ Bar: bit-exact for every integer plane and — because both sides compile the sa
 (include/rt_math.h) with contraction off — also for the fp32 planes; the stated tolerance of the path
 (BASELINE.json: per-pixel RMS <= 1e-4) is asserted as well so a future relaxation of exactness still has a gate.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -305,3 +307,30 @@ def test_full_size_properties(procedural_region, blue_noise, W, H, spp, depth):
     cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth, rows=rows)
     for name in cpu:
         assert np.array_equal(a1[name][rows[0]:rows[1]], cpu[name][rows[0]:rows[1]], equal_nan=True), name
+
+
+def test_bench_two_rank_rehearsal_assembles_the_same_frame():
+    """bench.py's N>1 path on a one-GPU box: 2 ranks share GPU 0 and gather over gloo (RCCL needs one GPU per rank; the
+    driver runs that).  The frame assembled on rank 0 must hash to the same value as the single-rank frame."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    common = ["--width", "200", "--height", "120", "--spp", "4", "--depth", "3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_SINGLE_DEVICE="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", "bench.py", "--gpus", "2"] + common, cwd=ROOT, capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
+    assert j1["config"]["frame_sha256_16"] == j2["config"]["frame_sha256_16"]
+    assert j1["config"]["rays_per_frame"] == j2["config"]["rays_per_frame"]
+    for j in (j1, j2):
+        for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                    "data", "config", "roofline", "cpu_baseline"):
+            assert key in j
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
