@@ -90,6 +90,28 @@ def host():
         lib.rth_copy_3d_auto_clip_u32.argtypes = [P, C.c_int, P, P, C.c_int]
         lib.rth_copy_3d_bounded_auto_clip_u32.argtypes = [P] * 7
         lib.rth_fill_slice_3d_auto_clip_u8.argtypes = [C.c_uint8, P, C.c_int, P, P]
+        lib.rth_chunk_codec_available.restype = C.c_int
+        lib.rth_chunk_file_name.argtypes = [C.c_long, C.c_long, C.c_long, P]
+        lib.rth_chunk_write.argtypes = [C.c_char_p, P, P]
+        lib.rth_chunk_read.argtypes = [C.c_char_p, P, P]
+        lib.rth_chunk_storage_new.argtypes = [C.c_char_p, C.c_uint64]
+        lib.rth_chunk_storage_new.restype = P
+        lib.rth_chunk_storage_free.argtypes = [P]
+        lib.rth_chunk_storage_free.restype = None
+        lib.rth_chunk_storage_borrow.argtypes = [P, C.c_long, C.c_long, C.c_long, P, P]
+        lib.rth_chunk_storage_stats.argtypes = [P, P, P]
+        lib.rth_tum_new.argtypes = [C.c_uint64]
+        lib.rth_tum_new.restype = P
+        lib.rth_tum_free.argtypes = [P]
+        lib.rth_tum_free.restype = None
+        lib.rth_tum_request.argtypes = [P, C.c_int, C.c_int]
+        lib.rth_tum_move_towards.argtypes = [P, P]
+        lib.rth_tum_pending.argtypes = [P]
+        lib.rth_tum_step.argtypes = [P]
+        lib.rth_tum_render_offset.argtypes = [P, P]
+        lib.rth_tum_region.argtypes = [P, P, P]
+        lib.rth_pipeline_enable_streaming.argtypes = [P, C.c_uint64, C.c_char_p]
+        lib.rth_pipeline_enable_streaming.restype = None
         lib.rth_compute_triple_euler_vector.argtypes = [C.c_float, C.c_float, P, P, P]
         lib.rth_game_new.argtypes = [C.c_int, P]
         lib.rth_game_new.restype = P

@@ -30,8 +30,8 @@ AMD_SRCS = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "rt_persist
             os.path.join(CSRC, "rt_api.hip")]
 AMD_DEPS = AMD_SRCS + [os.path.join(CSRC, "rt_device.hpp"), os.path.join(CSRC, "rt_kernels.hpp"),
                        os.path.join(INC, "rt_abi.h"), os.path.join(INC, "rt_math.h")]
-HOST_SRCS = [os.path.join(HOST, f) for f in ("world.cpp", "render.cpp", "host_capi.cpp")]
-HOST_DEPS = HOST_SRCS + [os.path.join(HOST, "world.hpp"), os.path.join(HOST, "render.hpp"), os.path.join(INC, "rt_abi.h")]
+HOST_SRCS = [os.path.join(HOST, f) for f in ("world.cpp", "chunk_storage.cpp", "terrain_upload.cpp", "render.cpp", "host_capi.cpp")]
+HOST_DEPS = HOST_SRCS + [os.path.join(HOST, f) for f in ("world.hpp", "render.hpp", "chunk_storage.hpp", "terrain_upload.hpp")] + [os.path.join(INC, "rt_abi.h")]
 BENCH_SRCS = [os.path.join(HOST, "rt_bench.cpp")]
 
 LIB_AMD = os.path.join(HERE, "librt_amd.so")
@@ -63,7 +63,7 @@ def build(force=False, verbose=True):
         built.append(LIB_AMD)
     if force or _stale(LIB_HOST, HOST_DEPS + [LIB_AMD]):
         _run([CXX] + CXX_FLAGS + ["-shared", "-o", LIB_HOST] + HOST_SRCS +
-             ["-L", HERE, "-lrt_amd", "-Wl,-rpath,$ORIGIN"])
+             ["-L", HERE, "-lrt_amd", "-ldl", "-Wl,-rpath,$ORIGIN"])
         built.append(LIB_HOST)
     if all(os.path.exists(s) for s in BENCH_SRCS) and (force or _stale(BENCH, BENCH_SRCS + [LIB_HOST, LIB_AMD])):
         _run([CXX] + CXX_FLAGS + ["-o", BENCH] + BENCH_SRCS + ["-L", HERE, "-lrt_host", "-lrt_amd", "-Wl,-rpath,$ORIGIN"])

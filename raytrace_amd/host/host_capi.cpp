@@ -4,7 +4,11 @@
 #include <cstring>
 #include <new>
 
+#include <vector>
+
+#include "chunk_storage.hpp"
 #include "render.hpp"
+#include "terrain_upload.hpp"
 #include "world.hpp"
 
 using namespace rt;
@@ -84,6 +88,77 @@ void rth_fill_slice_3d_auto_clip_u8(uint8_t value, uint8_t* dst, int dst_stride,
                                             {size3[0], size3[1], size3[2]});
 }
 
+// ---- chunk disk cache (chunk_storage.rs) ------------------------------------------------------------
+int rth_chunk_codec_available() { return world::ChunkStorage::codec_available() ? 1 : 0; }
+void rth_chunk_file_name(long cx, long cy, long cz, char* out49) {
+    std::string n = world::ChunkStorage::file_name(cx, cy, cz);
+    std::strncpy(out49, n.c_str(), 49);
+}
+int rth_chunk_write(const char* path, const uint32_t* materials, const uint8_t* minefield) {
+    world::PackedChunkData pc;
+    std::memcpy(pc.materials.data(), materials, sizeof(uint32_t) * world::kChunkVolume);
+    std::memcpy(pc.minefield.data(), minefield, world::kChunkVolume);
+    return world::ChunkStorage::write_packed_chunk_data(path, pc) ? RT_OK : RT_ERR_INVALID_ARG;
+}
+int rth_chunk_read(const char* path, uint32_t* materials, uint8_t* minefield) {
+    world::PackedChunkData pc;
+    if (!world::ChunkStorage::read_into_packed_chunk_data(path, pc)) return RT_ERR_INVALID_ARG;
+    std::memcpy(materials, pc.materials.data(), sizeof(uint32_t) * world::kChunkVolume);
+    std::memcpy(minefield, pc.minefield.data(), world::kChunkVolume);
+    return RT_OK;
+}
+void* rth_chunk_storage_new(const char* dir, uint64_t seed) { return new (std::nothrow) world::ChunkStorage(dir ? dir : "", seed); }
+void rth_chunk_storage_free(void* s) { delete static_cast<world::ChunkStorage*>(s); }
+int rth_chunk_storage_borrow(void* s, long cx, long cy, long cz, uint32_t* materials, uint8_t* minefield) {
+    const world::PackedChunkData& pc = static_cast<world::ChunkStorage*>(s)->borrow_packed_chunk_data(cx, cy, cz);
+    std::memcpy(materials, pc.materials.data(), sizeof(uint32_t) * world::kChunkVolume);
+    std::memcpy(minefield, pc.minefield.data(), world::kChunkVolume);
+    return RT_OK;
+}
+void rth_chunk_storage_stats(void* s, size_t* generated, size_t* loaded) {
+    *generated = static_cast<world::ChunkStorage*>(s)->generated();
+    *loaded = static_cast<world::ChunkStorage*>(s)->loaded();
+}
+
+// ---- TerrainUploadManager against a host-side toroidal region (CPU tests) -----------------------------
+struct HostTum {
+    render::TerrainUploadManager tum;
+    world::ChunkStorage chunks;
+    std::vector<uint32_t> materials;
+    std::vector<uint8_t> minefield;
+    HostTum(uint64_t seed) : chunks("", seed), materials(world::kRegionVolume), minefield(world::kRegionVolume) {
+        world::assemble_region_procedural(seed, materials.data(), minefield.data());
+    }
+};
+void* rth_tum_new(uint64_t seed) { return new (std::nothrow) HostTum(seed); }
+void rth_tum_free(void* t) { delete static_cast<HostTum*>(t); }
+void rth_tum_request(void* t, int axis, int increase) {
+    auto* h = static_cast<HostTum*>(t);
+    if (increase) h->tum.request_increase((render::Axis)axis); else h->tum.request_decrease((render::Axis)axis);
+}
+void rth_tum_move_towards(void* t, const long* center3) { static_cast<HostTum*>(t)->tum.request_move_towards(center3); }
+int rth_tum_pending(void* t) { return (int)static_cast<HostTum*>(t)->tum.pending(); }
+// Consumes one request; the slab is applied to the host region exactly like rt_upload_slice applies it on the device.
+int rth_tum_step(void* t) {
+    auto* h = static_cast<HostTum*>(t);
+    return h->tum.setup_next_request(h->chunks, [h](int axis, int off, const uint32_t* m, const uint8_t* f) {
+        const int R = world::kRegion, S = RT_SLICE_SIZE;
+        world::Dims3 shape{R, R, R};
+        (axis == 0 ? shape.x : (axis == 1 ? shape.y : shape.z)) = S;
+        world::Dims3 at{0, 0, 0};
+        (axis == 0 ? at.x : (axis == 1 ? at.y : at.z)) = off;
+        world::copy_3d(shape, m, shape, {0, 0, 0}, h->materials.data(), {R, R, R}, at);
+        world::copy_3d(shape, f, shape, {0, 0, 0}, h->minefield.data(), {R, R, R}, at);
+        return (int)RT_OK;
+    });
+}
+void rth_tum_render_offset(void* t, long* out3) { static_cast<HostTum*>(t)->tum.get_render_offset(out3); }
+void rth_tum_region(void* t, uint32_t* materials, uint8_t* minefield) {
+    auto* h = static_cast<HostTum*>(t);
+    std::memcpy(materials, h->materials.data(), sizeof(uint32_t) * world::kRegionVolume);
+    std::memcpy(minefield, h->minefield.data(), world::kRegionVolume);
+}
+
 // ---- camera / uniforms ------------------------------------------------------------------------------
 void rth_compute_triple_euler_vector(float heading, float pitch, float* forward3, float* up3, float* right3) {
     render::TripleEulerVector v = render::compute_triple_euler_vector(heading, pitch);
@@ -127,6 +202,9 @@ int rth_pipeline_wait(void* p) { return static_cast<render::Pipeline*>(p)->wait(
 RtContext* rth_pipeline_context(void* p) { return static_cast<render::Pipeline*>(p)->context(); }
 void rth_pipeline_uniforms(void* p, RtUniforms* out) { *out = static_cast<render::Pipeline*>(p)->uniforms(); }
 void rth_pipeline_set_seed(void* p, uint32_t seed) { static_cast<render::Pipeline*>(p)->set_seed(seed); }
+void rth_pipeline_enable_streaming(void* p, uint64_t seed, const char* dir) {
+    static_cast<render::Pipeline*>(p)->enable_terrain_streaming(seed, dir ? dir : "");
+}
 const char* rth_pipeline_last_error(void* p) { return static_cast<render::Pipeline*>(p)->last_error(); }
 
 }  // extern "C"

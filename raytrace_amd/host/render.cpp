@@ -48,6 +48,11 @@ Pipeline* create_instance(const RtConfig& cfg, const uint8_t* blue_noise_rgba8, 
 
 Pipeline::~Pipeline() { rt_destroy(ctx_); }
 
+void Pipeline::enable_terrain_streaming(uint64_t seed, const std::string& storage_dir) {
+    chunks_.reset(new world::ChunkStorage(storage_dir, seed));
+    tum_.reset(new TerrainUploadManager());
+}
+
 const char* Pipeline::last_error() const { return rt_last_error(ctx_); }
 
 int Pipeline::wait() { return rt_sync(ctx_); }
@@ -68,7 +73,17 @@ int Pipeline::draw_frame(game::Game& game) {
     int rc = rt_sync(ctx_);                                          // pipeline.rs:162-172
     if (rc != RT_OK) return rc;
     const Camera& camera = game.borrow_camera();
-    // pipeline.rs:174-189 (terrain streaming) is out of scope: the region is static, render_offset stays (0,0,0).
+    if (tum_) {                                                      // pipeline.rs:174-189
+        const long towards[3] = {(long)camera.origin[0], 0, (long)camera.origin[2]};   // (x, literal 0, z) — :175-179
+        tum_->request_move_towards(towards);
+        rc = tum_->setup_next_request(*chunks_, [this](int axis, int off, const uint32_t* m, const uint8_t* f) {
+            return rt_upload_slice(ctx_, axis, off, m, f);
+        });
+        if (rc != RT_OK) return rc;
+        long off[3];
+        tum_->get_render_offset(off);
+        for (int a = 0; a < 3; a++) render_offset_[a] = (int)off[a];
+    }
     TripleEulerVector v = compute_triple_euler_vector(camera.heading, camera.pitch);   // :191-193
     RtUniforms& u = uniforms_;
     for (int a = 0; a < 3; a++) {

@@ -4,10 +4,12 @@
 // (src/game/mod.rs:14-58,103-125).  Everything GPU-side goes through the C ABI in include/rt_abi.h.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/rt_abi.h"
+#include "terrain_upload.hpp"
 
 namespace rt::render {
 
@@ -64,6 +66,11 @@ class Pipeline {
     const RtUniforms& uniforms() const { return uniforms_; }
     void set_seed(uint32_t seed) { uniforms_.seed = seed; }
     const char* last_error() const;
+    // Terrain streaming (pipeline.rs:174-189): when enabled, every draw_frame asks the TerrainUploadManager to move towards
+    // the camera and uploads at most one slab; the render offset becomes the uniform block's `lr`.  Off by default
+    // (static region).  `storage_dir` empty = no disk cache.
+    void enable_terrain_streaming(uint64_t seed, const std::string& storage_dir);
+    TerrainUploadManager* terrain_upload_manager() { return tum_.get(); }
 
  private:
     friend Pipeline* create_instance(const RtConfig&, const uint8_t*, game::Game&, std::string*);
@@ -72,6 +79,8 @@ class Pipeline {
     RtUniforms uniforms_{};            // RenderData::raytrace_uniform_data, render_data.rs:134-162
     int spp_ = 1;
     int render_offset_[3] = {0, 0, 0}; // TerrainUploadManager::get_render_offset (terrain_upload.rs:30-47)
+    std::unique_ptr<TerrainUploadManager> tum_;
+    std::unique_ptr<world::ChunkStorage> chunks_;
 };
 
 // render::create_instance (mod.rs:36-43) -> Pipeline::new (pipeline.rs:36-76): creates the device context, uploads

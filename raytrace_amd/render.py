@@ -283,6 +283,10 @@ class Pipeline:
     def set_seed(self, seed):
         _lib.host().rth_pipeline_set_seed(self._h, C.c_uint32(int(seed)))
 
+    def enable_terrain_streaming(self, seed=0x5EED, storage_dir=""):
+        """pipeline.rs:174-189: every draw_frame moves the TerrainUploadManager towards the camera (<= 1 slab per frame)."""
+        _lib.host().rth_pipeline_enable_streaming(self._h, C.c_uint64(int(seed)), str(storage_dir).encode() if storage_dir else None)
+
     def close(self):
         if self._h:
             _lib.host().rth_pipeline_free(self._h)   # impl Drop for Pipeline, pipeline.rs:258-277

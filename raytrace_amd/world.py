@@ -113,3 +113,134 @@ def fill_slice_3d_auto_clip(value, target, target_stride, slice_start, slice_siz
     assert target.dtype == np.uint8
     _lib.host().rth_fill_slice_3d_auto_clip_u8(C.c_uint8(int(value)), _p(target), int(target_stride), _l3(slice_start),
                                                _i3(slice_size))
+
+
+# ---- chunk disk cache (src/world/chunk_storage.rs) --------------------------------------------------------------
+
+def chunk_codec_available():
+    return bool(_lib.host().rth_chunk_codec_available())
+
+
+def chunk_file_name(cx, cy, cz):
+    """chunk_storage.rs:37-40: three {:016X} of the isize chunk coordinates."""
+    buf = C.create_string_buffer(49)
+    _lib.host().rth_chunk_file_name(int(cx), int(cy), int(cz), buf)
+    return buf.value.decode()
+
+
+def write_chunk_file(path, materials, minefield):
+    """write_packed_chunk_data (chunk_storage.rs:42-55): LZ4 frame (level 4) of materials u32[64^3] then minefield u8[64^3]."""
+    materials = np.ascontiguousarray(materials, dtype=np.uint32).reshape(-1)
+    minefield = np.ascontiguousarray(minefield, dtype=np.uint8).reshape(-1)
+    assert materials.size == CHUNK_VOLUME and minefield.size == CHUNK_VOLUME
+    if _lib.host().rth_chunk_write(str(path).encode(), _p(materials), _p(minefield)) != 0:
+        raise IOError("cannot write %s" % path)
+
+
+def read_chunk_file(path):
+    """read_into_packed_chunk_data (chunk_storage.rs:57-68)."""
+    mats = np.zeros(CHUNK_VOLUME, dtype=np.uint32)
+    mine = np.zeros(CHUNK_VOLUME, dtype=np.uint8)
+    if _lib.host().rth_chunk_read(str(path).encode(), _p(mats), _p(mine)) != 0:
+        raise IOError("cannot read %s" % path)
+    return mats.reshape(64, 64, 64), mine.reshape(64, 64, 64)
+
+
+class ChunkStorage:
+    """world::ChunkStorage (chunk_storage.rs:13-152): generate-on-miss chunk cache with optional LZ4 files on disk."""
+
+    def __init__(self, storage_dir="", seed=DEFAULT_SEED):
+        self._h = C.c_void_p(_lib.host().rth_chunk_storage_new(str(storage_dir).encode() if storage_dir else None, C.c_uint64(seed)))
+
+    def borrow_packed_chunk_data(self, cx, cy, cz):
+        mats = np.zeros(CHUNK_VOLUME, dtype=np.uint32)
+        mine = np.zeros(CHUNK_VOLUME, dtype=np.uint8)
+        _lib.host().rth_chunk_storage_borrow(self._h, int(cx), int(cy), int(cz), _p(mats), _p(mine))
+        return mats.reshape(64, 64, 64), mine.reshape(64, 64, 64)
+
+    def stats(self):
+        g, l = C.c_size_t(), C.c_size_t()
+        _lib.host().rth_chunk_storage_stats(self._h, C.byref(g), C.byref(l))
+        return {"generated": g.value, "loaded": l.value}
+
+    def close(self):
+        if self._h:
+            _lib.host().rth_chunk_storage_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostTerrainUploadManager:
+    """TerrainUploadManager (terrain_upload.rs:49-368) driving a HOST copy of the toroidal region — what the pipeline
+    does on the device through rt_upload_slice, for CPU tests."""
+
+    def __init__(self, seed=DEFAULT_SEED):
+        self._h = C.c_void_p(_lib.host().rth_tum_new(C.c_uint64(seed)))
+
+    def request_increase(self, axis):
+        _lib.host().rth_tum_request(self._h, int(axis), 1)
+
+    def request_decrease(self, axis):
+        _lib.host().rth_tum_request(self._h, int(axis), 0)
+
+    def request_move_towards(self, center):
+        _lib.host().rth_tum_move_towards(self._h, (C.c_long * 3)(*[int(c) for c in center]))
+
+    def pending(self):
+        return int(_lib.host().rth_tum_pending(self._h))
+
+    def setup_next_request(self):
+        rc = _lib.host().rth_tum_step(self._h)
+        assert rc == 0
+
+    def get_render_offset(self):
+        o = (C.c_long * 3)()
+        _lib.host().rth_tum_render_offset(self._h, o)
+        return tuple(o[:])
+
+    def region(self):
+        mats = np.zeros(REGION_VOLUME, dtype=np.uint32)
+        mine = np.zeros(REGION_VOLUME, dtype=np.uint8)
+        _lib.host().rth_tum_region(self._h, _p(mats), _p(mine))
+        return mats.reshape(256, 256, 256), mine.reshape(256, 256, 256)
+
+    def close(self):
+        if self._h:
+            _lib.host().rth_tum_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def toroidal_region(render_offset, seed=DEFAULT_SEED):
+    """Expected texture content for a render offset (multiples of 16): texel t on each axis holds the world voxel v with
+    (v + 128) mod 256 == t inside the window [offset-128, offset+128).  Built from whole chunks, independently of the
+    TerrainUploadManager."""
+    cs = ChunkStorage("", seed)
+    mats = np.zeros((256, 256, 256), dtype=np.uint32)
+    mine = np.zeros((256, 256, 256), dtype=np.uint8)
+    lo = [int(o) - 128 for o in render_offset]
+    cr = [range(l // 64, (l + 255) // 64 + 1) for l in lo]
+    for cz in cr[2]:
+        for cy in cr[1]:
+            for cx in cr[0]:
+                m, f = cs.borrow_packed_chunk_data(cx, cy, cz)
+                c0 = (cx * 64, cy * 64, cz * 64)
+                s = [slice(max(c0[a], lo[a]) - c0[a], min(c0[a] + 64, lo[a] + 256) - c0[a]) for a in range(3)]
+                if any(x.stop <= x.start for x in s):
+                    continue
+                t = [(c0[a] + s[a].start + 128) % 256 for a in range(3)]
+                d = [slice(t[a], t[a] + (s[a].stop - s[a].start)) for a in range(3)]
+                mats[d[2], d[1], d[0]] = m[s[2], s[1], s[0]]
+                mine[d[2], d[1], d[0]] = f[s[2], s[1], s[0]]
+    cs.close()
+    return mats, mine
