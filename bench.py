@@ -152,30 +152,30 @@ def main():
     bpp = {abi.RT_BUF_LIGHTING_RGBA16: 8, abi.RT_BUF_DEPTH_R16UI: 2, abi.RT_BUF_NORMAL_R8UI: 1, abi.RT_BUF_ALBEDO_RGBA8: 4,
            abi.RT_BUF_EMISSION_RGBA8: 4, abi.RT_BUF_FOG_RGBA8: 4}
     if world > 1:
-        local_views = {b: torch.as_tensor(_DevArray(ctx.device_ptr(b), ctx.buffer_bytes(b)), device=dev) for b in gather_ids}
-        gathered = {b: torch.empty(world * ctx.buffer_bytes(b), dtype=torch.uint8, device=dev) if rank == 0 else None
-                    for b in gather_ids}
+        # one collective per frame: the six planes are one contiguous block on every rank (rt_gbuffer_ptr)
+        gbytes = ctx.gbuffer_bytes()
+        local_view = torch.as_tensor(_DevArray(ctx.gbuffer_ptr(), gbytes), device=dev)
+        gathered = torch.empty(world * gbytes, dtype=torch.uint8, device=dev) if rank == 0 else None
         frames = {b: torch.empty(W * H * bpp[b], dtype=torch.uint8, device=dev) if rank == 0 else None for b in gather_ids}
 
     def step():
         ctx.draw_frame(u)
         if world > 1:
-            for b in gather_ids:
-                if backend == "nccl":
-                    if rank == 0:
-                        dist.gather(local_views[b], list(gathered[b].chunk(world)), dst=0)
-                    else:
-                        dist.gather(local_views[b], None, dst=0)
-                else:   # rehearsal backend: stage through host memory
-                    host = local_views[b].cpu()
-                    if rank == 0:
-                        parts = [torch.empty_like(host) for _ in range(world)]
-                        dist.gather(host, parts, dst=0)
-                        gathered[b].copy_(torch.cat(parts))
-                    else:
-                        dist.gather(host, None, dst=0)
+            if backend == "nccl":
                 if rank == 0:
-                    ctx.untile(b, gathered[b].data_ptr(), world, frames[b].data_ptr())
+                    dist.gather(local_view, list(gathered.chunk(world)), dst=0)
+                else:
+                    dist.gather(local_view, None, dst=0)
+            else:   # rehearsal backend: stage through host memory
+                host = local_view.cpu()
+                if rank == 0:
+                    parts = [torch.empty_like(host) for _ in range(world)]
+                    dist.gather(host, parts, dst=0)
+                    gathered.copy_(torch.cat(parts))
+                else:
+                    dist.gather(host, None, dst=0)
+            if rank == 0:
+                ctx.untile_gbuffer(gathered.data_ptr(), world, [frames[b].data_ptr() for b in gather_ids])
 
     def fence():
         if world > 1:
@@ -185,17 +185,19 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if args.warmup > 0:
+        ctx.timing()      # drop the warm-up frames' launch events
     trace_ms = 0.0
     trace_launches = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # per-launch HIP events of this frame (recorded on the stream the kernels run on)
-        tm = ctx.timing()
-        trace_ms += tm.trace_ms
-        trace_launches += tm.trace_launches
     fence()
     elapsed = time.perf_counter() - t0
+    # per-launch HIP events of the K timed frames (recorded on the stream the kernels run on; read after the fence)
+    tm = ctx.timing()
+    trace_ms += tm.trace_ms
+    trace_launches += tm.trace_launches
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     sums = torch.tensor([float(rays_local), float(trace_bytes_local), float(balg_local), float(ref_equiv_rays_local)],

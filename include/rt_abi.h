@@ -164,7 +164,8 @@ typedef struct RtCounters {
     uint64_t frames;
 } RtCounters;
 
-/* HIP-event timings of the last rt_draw_frame (valid after rt_sync), milliseconds. */
+/* HIP-event timings, milliseconds.  frame_ms = the last rt_draw_frame; the per-launch sums (RT_FLAG_TIMING) cover
+ * every frame drawn since the previous rt_get_timing call. */
 typedef struct RtTiming {
     float    frame_ms;        /* whole frame on the context's stream                      */
     float    trace_ms;        /* sum of traversal-kernel launches                         */
@@ -230,6 +231,15 @@ int rt_tile_capacity(RtContext* ctx);
 /* Scatter `world` gathered tile-major planes (rank-major: world x capacity x 64 px x bpp, device
  * memory) into a row-major full-frame plane (device memory) on this context's stream. */
 int rt_untile(RtContext* ctx, int buffer_id, const void* gathered_dev, int world, void* frame_dev);
+
+/* The six reference-format planes (ids 0..5) of a context are one contiguous device block (each plane padded to 256 B),
+ * so a multi-GPU host gathers a frame with ONE collective: rt_gbuffer_ptr/bytes give the block, rt_gbuffer_offset the
+ * start of plane `id` inside it.  rt_untile_gbuffer scatters `world` gathered blocks (rank-major, device memory) into six
+ * row-major full-frame planes frames_dev[0..5] (device pointers; NULL entries are skipped). */
+void*  rt_gbuffer_ptr(RtContext* ctx);
+size_t rt_gbuffer_bytes(RtContext* ctx);
+size_t rt_gbuffer_offset(RtContext* ctx, int buffer_id);
+int rt_untile_gbuffer(RtContext* ctx, const void* gathered_dev, int world, void* const* frames_dev);
 
 /* The six bilateral_denoise.comp dispatches recorded at pipeline.rs:98-115 (sizes 1,2,4,8,8,16, ping/pong descriptor
  * sets): filters RT_BUF_LIGHTING_RGBA16 in place using the depth and normal planes.  faithful != 0 reproduces the

@@ -13,7 +13,8 @@ LIB_HOST_PATH = os.path.join(HERE, "librt_host.so")
 ABI_SYMBOLS = (
     "rt_create", "rt_destroy", "rt_last_error", "rt_upload_world", "rt_upload_slice", "rt_upload_noise",
     "rt_draw_frame", "rt_sync", "rt_readback", "rt_buffer_bytes", "rt_device_ptr", "rt_set_stream",
-    "rt_tile_count", "rt_tile_capacity", "rt_untile", "rt_denoise", "rt_finalize", "rt_get_counters", "rt_reset_counters", "rt_get_timing",
+    "rt_tile_count", "rt_tile_capacity", "rt_untile", "rt_gbuffer_ptr", "rt_gbuffer_bytes", "rt_gbuffer_offset",
+    "rt_untile_gbuffer", "rt_denoise", "rt_finalize", "rt_get_counters", "rt_reset_counters", "rt_get_timing",
     "rt_abi_version",
 )
 
@@ -55,6 +56,14 @@ def amd():
         lib.rt_tile_count.argtypes = [P]
         lib.rt_tile_capacity.argtypes = [P]
         lib.rt_untile.argtypes = [P, C.c_int, P, C.c_int, P]
+        lib.rt_gbuffer_ptr.argtypes = [P]
+        lib.rt_gbuffer_ptr.restype = P
+        lib.rt_gbuffer_bytes.argtypes = [P]
+        lib.rt_gbuffer_bytes.restype = C.c_size_t
+        lib.rt_gbuffer_offset.argtypes = [P, C.c_int]
+        lib.rt_gbuffer_offset.restype = C.c_size_t
+        lib.rt_untile_gbuffer.argtypes = [P, P, C.c_int, P]
+        lib.rt_untile_gbuffer.restype = C.c_int
         lib.rt_denoise.argtypes = [P, C.c_int]
         lib.rt_finalize.argtypes = [P]
         lib.rt_get_counters.argtypes = [P, C.POINTER(RtCounters)]
@@ -62,7 +71,8 @@ def amd():
         lib.rt_get_timing.argtypes = [P, C.POINTER(RtTiming)]
         lib.rt_abi_version.restype = C.c_uint32
         for name in ("rt_upload_world", "rt_upload_slice", "rt_upload_noise", "rt_draw_frame", "rt_sync", "rt_readback",
-                     "rt_set_stream", "rt_tile_count", "rt_tile_capacity", "rt_untile", "rt_denoise", "rt_finalize", "rt_get_counters",
+                     "rt_set_stream", "rt_tile_count", "rt_tile_capacity", "rt_untile", "rt_untile_gbuffer", "rt_denoise", "rt_finalize",
+                     "rt_get_counters",
                      "rt_reset_counters", "rt_get_timing"):
             getattr(lib, name).restype = C.c_int
         _amd = lib

@@ -45,6 +45,9 @@ struct RtContext {
     size_t plane_pixels = 0;   // pixels per output plane
 
     void* planes[RT_BUF_COUNT] = {};
+    void* gbuffer = nullptr;            // planes 0..5 back to back (256-byte aligned each)
+    size_t gbuffer_offset[6] = {};
+    size_t gbuffer_bytes = 0;
     void* lighting_pong = nullptr;   // lighting_pong_buffer, render_data.rs:178-182
 
     // wavefront pipeline state
@@ -302,11 +305,25 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     RT_HIP_CREATE(dev_alloc(c, &c->d_counters, 1));
     RT_HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(rtd::DevCounters)));
 
-    for (int b = 0; b < RT_BUF_COUNT; b++) {
-        uint8_t* p = nullptr;
-        RT_HIP_CREATE(dev_alloc(c, &p, c->plane_pixels * kBytesPerPixel[b]));
-        RT_HIP_CREATE(hipMemset(p, 0, c->plane_pixels * kBytesPerPixel[b]));
-        c->planes[b] = p;
+    {   // the six reference-format planes live in ONE block (each padded to 256 B) so a multi-GPU host can gather them
+        // with a single collective; the other planes are separate allocations
+        size_t off = 0;
+        for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++) {
+            c->gbuffer_offset[b] = off;
+            off += (c->plane_pixels * kBytesPerPixel[b] + 255) / 256 * 256;
+        }
+        c->gbuffer_bytes = off;
+        uint8_t* block = nullptr;
+        RT_HIP_CREATE(dev_alloc(c, &block, off));
+        RT_HIP_CREATE(hipMemset(block, 0, off));
+        c->gbuffer = block;
+        for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++) c->planes[b] = block + c->gbuffer_offset[b];
+        for (int b = RT_BUF_FOG_RGBA8 + 1; b < RT_BUF_COUNT; b++) {
+            uint8_t* p = nullptr;
+            RT_HIP_CREATE(dev_alloc(c, &p, c->plane_pixels * kBytesPerPixel[b]));
+            RT_HIP_CREATE(hipMemset(p, 0, c->plane_pixels * kBytesPerPixel[b]));
+            c->planes[b] = p;
+        }
     }
 
     { uint8_t* p = nullptr; RT_HIP_CREATE(dev_alloc(c, &p, c->plane_pixels * 8)); c->lighting_pong = p; }
@@ -443,11 +460,6 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const rtd::Frame f = frame_of(ctx, u);
     const bool count = (ctx->cfg.flags & RT_FLAG_COUNTERS) != 0;
-    if (ctx->cfg.flags & RT_FLAG_TIMING) {
-        // the previous frame's events are about to be reused
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->ev_used = 0;
-    }
     RT_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
     int rc = RT_OK;
     if (ctx->kernel == RT_KERNEL_MEGA) {
@@ -576,6 +588,28 @@ int rt_finalize(RtContext* ctx) {
     return RT_OK;
 }
 
+void* rt_gbuffer_ptr(RtContext* ctx) { return ctx ? ctx->gbuffer : nullptr; }
+size_t rt_gbuffer_bytes(RtContext* ctx) { return ctx ? ctx->gbuffer_bytes : 0; }
+size_t rt_gbuffer_offset(RtContext* ctx, int id) {
+    if (!ctx || id < 0 || id > RT_BUF_FOG_RGBA8) return 0;
+    return ctx->gbuffer_offset[id];
+}
+
+int rt_untile_gbuffer(RtContext* ctx, const void* gathered_dev, int world, void* const* frames_dev) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!gathered_dev || !frames_dev || world < 1) return fail(ctx, RT_ERR_INVALID_ARG, "rt_untile_gbuffer: bad argument");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int capacity = (ctx->ntiles_total + world - 1) / world;
+    if (world == ctx->cfg.tile_world && capacity != ctx->tile_capacity) return fail(ctx, RT_ERR_INVALID_ARG, "rt_untile_gbuffer: capacity mismatch");
+    for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++) {
+        if (!frames_dev[b]) continue;
+        RT_HIP(ctx, rtd::launch_untile_strided((const uint8_t*)gathered_dev + ctx->gbuffer_offset[b], ctx->gbuffer_bytes, frames_dev[b], world,
+                                               capacity, ctx->tiles_x, ctx->tiles_y, ctx->cfg.width, ctx->cfg.height,
+                                               (int)kBytesPerPixel[b], ctx->stream));
+    }
+    return RT_OK;
+}
+
 int rt_get_counters(RtContext* ctx, RtCounters* out) {
     if (!ctx || !out) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -611,12 +645,14 @@ int rt_get_timing(RtContext* ctx, RtTiming* out) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RT_HIP(ctx, hipEventElapsedTime(&out->frame_ms, ctx->ev_frame0, ctx->ev_frame1));
+    // per-launch events accumulate over every frame drawn since the previous rt_get_timing (no per-frame sync needed)
     for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
         float ms = 0.0f;
         RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
         if (ctx->ev_kind[i / 2] == 0) { out->trace_ms += ms; out->trace_launches++; }
         else { out->shade_ms += ms; out->other_launches++; }
     }
+    ctx->ev_used = 0;
     return RT_OK;
 }
 

@@ -448,9 +448,10 @@ __global__ __launch_bounds__(256) void k_resolve(Frame f, const float4* __restri
     store_lighting(pl, pix.out_index, v3(v.x, v.y, v.z), f.spp);
 }
 
-// Gathered planes are rank-major: [world][capacity tiles][64 px][bpp bytes].  Tile j of rank r is global tile r + j*world.
-__global__ __launch_bounds__(256) void k_untile(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ frame, int world,
-                                                int capacity, int tiles_x, int tiles_y, int width, int height, int bpp) {
+// Gathered planes are rank-major: rank r's plane [capacity tiles][64 px][bpp bytes] starts at r * rank_stride.
+// Tile j of rank r is global tile r + j*world.
+__global__ __launch_bounds__(256) void k_untile(const uint8_t* __restrict__ gathered, size_t rank_stride, uint8_t* __restrict__ frame,
+                                                int world, int capacity, int tiles_x, int tiles_y, int width, int height, int bpp) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // one thread per gathered pixel
     const uint32_t total = (uint32_t)world * (uint32_t)capacity * 64u;
     if (i >= total) return;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256) void k_untile(const uint8_t* __restrict__ gath
     if (t >= (uint32_t)(tiles_x * tiles_y)) return;
     const int px = (int)(t % (uint32_t)tiles_x) * 8 + (int)(l & 7u), py = (int)(t / (uint32_t)tiles_x) * 8 + (int)(l >> 3);
     if (px >= width || py >= height) return;
-    const uint8_t* s = gathered + (size_t)i * bpp;
+    const uint8_t* s = gathered + (size_t)r * rank_stride + ((size_t)j * 64u + l) * bpp;
     uint8_t* d = frame + ((size_t)py * width + px) * bpp;
     for (int k = 0; k < bpp; k++) d[k] = s[k];
 }
@@ -528,13 +529,19 @@ hipError_t launch_resolve(const Frame& f, const float4* acc, const Planes& pl, u
     return hipGetLastError();
 }
 
-hipError_t launch_untile(const void* gathered, void* frame, int world, int capacity, int tiles_x, int tiles_y, int width,
-                         int height, int bpp, hipStream_t st) {
+hipError_t launch_untile_strided(const void* gathered, size_t rank_stride, void* frame, int world, int capacity, int tiles_x,
+                                 int tiles_y, int width, int height, int bpp, hipStream_t st) {
     const uint32_t total = (uint32_t)world * (uint32_t)capacity * 64u;
     if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_untile, dim3((total + 255u) / 256u), dim3(256), 0, st, (const uint8_t*)gathered, (uint8_t*)frame, world,
-                       capacity, tiles_x, tiles_y, width, height, bpp);
+    hipLaunchKernelGGL(k_untile, dim3((total + 255u) / 256u), dim3(256), 0, st, (const uint8_t*)gathered, rank_stride, (uint8_t*)frame,
+                       world, capacity, tiles_x, tiles_y, width, height, bpp);
     return hipGetLastError();
+}
+
+hipError_t launch_untile(const void* gathered, void* frame, int world, int capacity, int tiles_x, int tiles_y, int width,
+                         int height, int bpp, hipStream_t st) {
+    return launch_untile_strided(gathered, (size_t)capacity * 64u * (size_t)bpp, frame, world, capacity, tiles_x, tiles_y, width,
+                                 height, bpp, st);
 }
 
 }  // namespace rtd

@@ -92,6 +92,8 @@ hipError_t launch_shadeN(const Scene& sc, const Frame& f, const ShadeArgs& a, in
 hipError_t launch_accumulate(const float* plx, const float* ply, const float* plz, float4* acc, uint32_t npix_pad,
                              uint32_t nsamples, bool first_batch, hipStream_t st);
 hipError_t launch_resolve(const Frame& f, const float4* acc, const Planes& pl, uint32_t npix_pad, hipStream_t st);
+hipError_t launch_untile_strided(const void* gathered, size_t rank_stride, void* frame, int world, int capacity, int tiles_x,
+                                 int tiles_y, int width, int height, int bpp, hipStream_t st);
 hipError_t launch_untile(const void* gathered, void* frame, int world, int capacity, int tiles_x, int tiles_y, int width,
                          int height, int bpp, hipStream_t st);
 

@@ -143,6 +143,17 @@ class Context:
         self._check(self._lib.rt_untile(self._h, int(buffer_id), C.c_void_p(gathered_dev_ptr), int(world),
                                         C.c_void_p(frame_dev_ptr)))
 
+    def gbuffer_ptr(self):
+        return self._lib.rt_gbuffer_ptr(self._h)
+
+    def gbuffer_bytes(self):
+        return int(self._lib.rt_gbuffer_bytes(self._h))
+
+    def untile_gbuffer(self, gathered_dev_ptr, world, frame_dev_ptrs):
+        """Scatter `world` gathered G-buffer blocks into six row-major planes (device pointers, None to skip)."""
+        arr = (C.c_void_p * 6)(*[C.c_void_p(p) if p else None for p in frame_dev_ptrs])
+        self._check(self._lib.rt_untile_gbuffer(self._h, C.c_void_p(gathered_dev_ptr), int(world), arr))
+
     # -- post passes (pipeline.rs:98-123) ----------------------------------------------------------------
     def denoise(self, faithful=True):
         self._check(self._lib.rt_denoise(self._h, 1 if faithful else 0))
