@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, time
 from raytrace_amd import abi, render, world
 noise = np.fromfile('tests/golden/blue_noise_512.rgba', dtype=np.uint8)
