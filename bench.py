@@ -232,7 +232,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mrays/s at 1920x1080 spp=64 (rays actually traced: primary + shadow + diffuse)",
+            "metric": "Mrays/s at %dx%d spp=%d (rays actually traced: primary + shadow + diffuse)" % (W, H, SPP),
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
