@@ -49,21 +49,23 @@ def parse_args():
     ap.add_argument("--no-cache-primary", dest="cache_primary", action="store_false",
                     help="re-trace the (seed-independent) primary ray for every sample, like spp reference frames would")
     ap.set_defaults(cache_primary=True)
+    ap.add_argument("--region", type=int, default=256, choices=[256, 512, 1024],
+                    help="region edge: 256 = the reference; 1024 = the 5 GiB stress scene of config C5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(mats, mine, noise, u, width, height, spp, depth, target_s=12.0):
+def cpu_baseline(mats, mine, noise, u, width, height, spp, depth, target_s=12.0, region=256):
     """The CPU oracle (a port: the reference has no CPU renderer) timed on this host's cores on a
     bounded sample of the same workload: the full frame at as many of the workload's samples as fit in ~target_s."""
     from oracle import pyoracle as po
     cores = os.cpu_count() or 1
     t0 = time.perf_counter()
-    _, cn = po.render(mats, mine, noise, u, width, height, 1, depth)          # calibration: 1 sample
+    _, cn = po.render(mats, mine, noise, u, width, height, 1, depth, region=region)          # calibration: 1 sample
     dt1 = max(time.perf_counter() - t0, 1e-3)
     n = int(max(1, min(spp, target_s / dt1)))
     t0 = time.perf_counter()
-    _, cn = po.render(mats, mine, noise, u, width, height, n, depth)
+    _, cn = po.render(mats, mine, noise, u, width, height, n, depth, region=region)
     dt = time.perf_counter() - t0
     return {"value": round(cn.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "oracle (scalar fp32 C++ restatement of raytrace.comp, OpenMP dynamic over rows, %d threads): %dx%d, "
@@ -106,13 +108,16 @@ def main():
     kernel = {"persistent": abi.RT_KERNEL_PERSISTENT, "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
     noise = np.fromfile(os.path.join(ROOT, "tests", "golden", "blue_noise_512.rgba"), dtype=np.uint8)
-    mats, mine = rt_world.generate_region(rt_world.DEFAULT_SEED)
-    pose = render.DEFAULT_POSE
+    REGION = args.region
+    mats, mine = rt_world.generate_region(rt_world.DEFAULT_SEED, region=REGION)
+    pose = dict(render.DEFAULT_POSE)
+    scale = REGION // 256            # C5 pose (-120,-512,400) = the default pose scaled with the region
+    pose["origin"] = tuple(c * scale for c in pose["origin"])
     u = render.camera_uniforms(pose["origin"], pose["heading"], pose["pitch"], pose["sun_angle"], seed=1)
 
     def make_ctx(flags):
         cfg = render.make_config(W, H, spp=SPP, depth=D, device=local_rank, tile_rank=rank, tile_world=world,
-                                 kernel=kernel, flags=flags | xflags)
+                                 kernel=kernel, flags=flags | xflags, region=REGION)
         ctx = render.Context(cfg)
         ctx.upload_world(mats, mine)
         ctx.upload_noise(noise)
@@ -133,7 +138,7 @@ def main():
         # the dominant kernel (k_persist) walks only shadow/diffuse rays; the primary prepass (k_primary) is a separate,
         # untimed-for-roofline launch: subtract its share, measured with a depth-0 counting frame
         cfg0 = render.make_config(W, H, spp=SPP, depth=0, device=local_rank, tile_rank=rank, tile_world=world,
-                                  kernel=kernel, flags=abi.RT_FLAG_COUNTERS | xflags)
+                                  kernel=kernel, flags=abi.RT_FLAG_COUNTERS | xflags, region=REGION)
         c0 = render.Context(cfg0)
         c0.upload_world(mats, mine)
         c0.upload_noise(noise)
@@ -226,7 +231,7 @@ def main():
         achieved = (trace_bytes_local * args.steps) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r1.json")
-        if os.path.exists(tpath) and (W, H, SPP, D) == (1920, 1080, 64, 4) and world == 1:
+        if os.path.exists(tpath) and (W, H, SPP, D, REGION) == (1920, 1080, 64, 4, 256) and world == 1:
             try:
                 traffic = json.load(open(tpath)).get("k_%s_hbm_bytes_per_launch" % {"persistent": "persist", "wavefront": "trace", "mega": "mega"}[args.kernel])
             except Exception:
@@ -236,8 +241,8 @@ def main():
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d spp=%d depth=%d, procedural 256^3 region seed 0x5EED, pose (-30,-128,100) h=pi/2 p=0 sun=0"
-                                   % (W, H, SPP, D), "kernel": args.kernel, "rays_per_frame": int(rays_total), "reference_equivalent_rays_per_frame": int(ref_rays_total),
+            "config": {"workload": "%dx%d spp=%d depth=%d, procedural %d^3 region seed 0x5EED, pose (%g,%g,%g) h=pi/2 p=0 sun=0"
+                                   % ((W, H, SPP, D, REGION) + tuple(pose["origin"])), "kernel": args.kernel, "rays_per_frame": int(rays_total), "reference_equivalent_rays_per_frame": int(ref_rays_total),
                        "algorithmic_bytes_per_frame": int(balg_total), "parallelism": "tiles%d" % world,
                        "primary_cache": bool(args.cache_primary), "frame_sha256_16": frame_sha},
             "roofline": {"bound": "hbm", "kernel": {"persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}[args.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -247,7 +252,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(trace_bytes_local / max(trace_launches // max(args.steps, 1), 1))},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mats, mine, noise, u, W, H, SPP, D)
+            out["cpu_baseline"] = cpu_baseline(mats, mine, noise, u, W, H, SPP, D, region=REGION)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

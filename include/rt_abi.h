@@ -117,7 +117,7 @@ typedef struct RtConfig {
     uint32_t struct_size;   /* sizeof(RtConfig), for forward compatibility */
     int32_t  width;
     int32_t  height;
-    int32_t  region;        /* must be RT_ROOT_BLOCK_SIZE (256) in this version */
+    int32_t  region;        /* region edge R: 256 = the reference (ROOT_BLOCK_WIDTH); 512 and 1024 are extensions (C5) */
     int32_t  spp;           /* >= 1 */
     int32_t  depth;         /* 0..RT_MAX_DEPTH */
     int32_t  device;        /* HIP device ordinal */
@@ -189,14 +189,14 @@ void rt_destroy(RtContext* ctx);
 const char* rt_last_error(RtContext* ctx);
 
 /* RenderData::initialize -> full-region upload (render_data.rs:269-301; formats :54-108).
- * materials: u32[256^3], minefield: u8[256^3], both x-fastest (util.rs:104-106), texel = world+128
- * (render_data.rs:221-236). The library re-tiles into 4^3 bricks on the device. */
+ * materials: u32[R^3], minefield: u8[R^3] (R = cfg.region, 256 in the reference), both x-fastest (util.rs:104-106),
+ * texel = world + R/2 (render_data.rs:221-236). The library re-tiles into 4^3 bricks on the device. */
 int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* minefield);
 
 /* TerrainUploadManager::upload_slice (terrain_upload.rs:84-275) -> vkCmdCopyBufferToImage with an
  * offset (command_buffer.rs:262-298): replace one 16-thick slab of the region.  axis 0/1/2 = x/y/z;
  * texel_offset (multiple of 16, < 256) is the slab's start along that axis; the data is a dense box of
- * extent (16,256,256) / (256,16,256) / (256,256,16), x fastest (terrain_upload.rs:96-100). */
+ * extent (16,R,R) / (R,16,R) / (R,R,16), x fastest (terrain_upload.rs:96-100). */
 int rt_upload_slice(RtContext* ctx, int axis, int texel_offset,
                     const uint32_t* materials, const uint8_t* minefield);
 

@@ -65,12 +65,12 @@ PLANES = {"lighting_rgba16": (np.uint16, 4), "depth_r16": (np.uint16, 1), "norma
           "lighting_f32": (np.float32, 4), "fog_f32": (np.float32, 4), "depth_f32": (np.float32, 1)}
 
 
-def render(materials, minefield, noise, uniforms, width, height, spp=1, depth=2, rows=None, threads=0):
+def render(materials, minefield, noise, uniforms, width, height, spp=1, depth=2, rows=None, threads=0, region=256):
     """Render with the oracle. Returns (dict of planes [H,W,(C)], RtCounters)."""
     materials = np.ascontiguousarray(materials, dtype=np.uint32).reshape(-1)
     minefield = np.ascontiguousarray(minefield, dtype=np.uint8).reshape(-1)
     noise = np.ascontiguousarray(noise, dtype=np.uint8).reshape(-1)
-    assert materials.size == 256 ** 3 and minefield.size == 256 ** 3 and noise.size == 512 * 512 * 4
+    assert materials.size == region ** 3 and minefield.size == region ** 3 and noise.size == 512 * 512 * 4
     y0, y1 = rows if rows is not None else (0, height)
     planes = {}
     out = RtOracleOut()
@@ -79,8 +79,8 @@ def render(materials, minefield, noise, uniforms, width, height, spp=1, depth=2,
         planes[name] = np.zeros(shape, dtype=dt)
         setattr(out, name, planes[name].ctypes.data)
     cn = RtCounters()
-    rc = lib().rt_oracle_render(_p(materials), _p(minefield), _p(noise), C.byref(uniforms), int(width), int(height),
-                                int(spp), int(depth), int(y0), int(y1), int(threads), C.byref(out), C.byref(cn))
+    rc = lib().rt_oracle_render_region(_p(materials), _p(minefield), _p(noise), C.byref(uniforms), int(region), int(width),
+                                       int(height), int(spp), int(depth), int(y0), int(y1), int(threads), C.byref(out), C.byref(cn))
     if rc != 0:
         raise RuntimeError("rt_oracle_render failed: %d" % rc)
     return planes, cn

@@ -35,7 +35,7 @@
 
 namespace {
 
-constexpr int R = RT_ROOT_BLOCK_SIZE;          // raytrace.comp:37 ROOT_BLOCK_WIDTH
+constexpr int kDefaultRegion = RT_ROOT_BLOCK_SIZE;   // raytrace.comp:37 ROOT_BLOCK_WIDTH (256); 512/1024 are the build's extension
 constexpr uint32_t NORMAL_x = 0, NORMAL_y = 2, NORMAL_z = 4;  // raytrace.comp:45-47
 
 struct vec3 { float x, y, z; };
@@ -61,9 +61,10 @@ struct Counters {
 };
 
 struct Scene {
-    const uint32_t* materials;  // u32[R^3], x fastest (src/util.rs:104-106), texel = world + 128
+    const uint32_t* materials;  // u32[R^3], x fastest (src/util.rs:104-106), texel = world + R/2
     const uint8_t* minefield;   // u8[R^3]
     const uint8_t* noise;       // RGBA8 512x512
+    int R = kDefaultRegion;     // ROOT_BLOCK_WIDTH
 };
 
 // HitResult — raytrace.comp:62-69
@@ -80,7 +81,7 @@ struct HitResult {
 
 // texel index of an unnormalised NEAREST lookup on one axis; -1 = outside (CLAMP_TO_BORDER) or NaN.
 // Sampler: render_data.rs:90-101 (minefield), structures.rs:382-461.
-inline int border_texel(float c) {
+inline int border_texel(float c, int R) {
     if (!(c >= 0.0f && c < (float)R)) return -1;
     return (int)c;  // floor for c >= 0
 }
@@ -93,10 +94,11 @@ static uint64_t g_fetch_hist[2][32];
 // get_step — raytrace.comp:78-80.  Border colour INT_OPAQUE_BLACK => 0 (render_data.rs:97-98).
 inline uint32_t get_step(const Scene& sc, vec3 tex_pos, Counters& cn) {
     cn.minefield_fetches++;
-    int ix = border_texel(tex_pos.x), iy = border_texel(tex_pos.y), iz = border_texel(tex_pos.z);
+    const int R = sc.R;
+    int ix = border_texel(tex_pos.x, R), iy = border_texel(tex_pos.y, R), iz = border_texel(tex_pos.z, R);
     if ((ix | iy | iz) < 0) { cn.border_fetches++; return 0; }
     const uint8_t v = sc.minefield[((size_t)iz * R + iy) * R + ix];
-    if (g_uniform4) g_fetch_hist[g_uniform4[((size_t)(iz >> 2) * 64 + (iy >> 2)) * 64 + (ix >> 2)] ? 1 : 0][v & 31]++;
+    if (g_uniform4 && R == 256) g_fetch_hist[g_uniform4[((size_t)(iz >> 2) * 64 + (iy >> 2)) * 64 + (ix >> 2)] ? 1 : 0][v & 31]++;
     return v;
 }
 
@@ -104,9 +106,10 @@ inline uint32_t get_step(const Scene& sc, vec3 tex_pos, Counters& cn) {
 // (normalised coordinates, NEAREST, CLAMP_TO_BORDER): texel = floor(u * 256).
 inline uint32_t get_material(const Scene& sc, vec3 p, Counters& cn) {
     cn.material_fetches++;
+    const int R = sc.R;
     float u[3] = {rtm_mod(p.x / (float)R, 1.0f), rtm_mod(p.y / (float)R, 1.0f), rtm_mod(p.z / (float)R, 1.0f)};
     int t[3];
-    for (int a = 0; a < 3; a++) t[a] = border_texel(u[a] * (float)R);
+    for (int a = 0; a < 3; a++) t[a] = border_texel(u[a] * (float)R, R);
     if ((t[0] | t[1] | t[2]) < 0) return 0;
     return sc.materials[((size_t)t[2] * R + t[1]) * R + t[0]];
 }
@@ -129,7 +132,7 @@ HitResult trace_ray(const Scene& sc, const int32_t lr[3], vec3 origin, vec3 dire
     vec3 muls = {direction.x > 0 ? -1.0f : 1.0f, direction.y > 0 ? -1.0f : 1.0f,
                  direction.z > 0 ? -1.0f : 1.0f};                             // :94-98
     vec3 current_rotation = {(float)lr[0], (float)lr[1], (float)lr[2]};       // :104
-    const float W = (float)R;
+    const float W = (float)sc.R;
     vec3 pos_offset = {W / 2, W / 2, W / 2};                                  // :105
     auto texpos = [&](vec3 p) {
         vec3 q = p + pos_offset;
@@ -327,8 +330,8 @@ PixelOut shade_pixel(const Scene& sc, const RtUniforms& u, const FrameConsts& fc
     vec3 up = {u.up[0], u.up[1], u.up[2]}, right = {u.right[0], u.right[1], u.right[2]};
     vec3 ray_start = origin;
     vec3 ray_direction = normalize(forward + right * sx + up * sy);
-    if (-ray_start.y > (float)R / 2.0f) {
-        float space = -ray_start.y - ((float)R / 2.0f);
+    if (-ray_start.y > (float)sc.R / 2.0f) {
+        float space = -ray_start.y - ((float)sc.R / 2.0f);
         ray_start = ray_start + ray_direction * (space / ray_direction.y + 0.0001f);
     }
     PixelOut o;
@@ -367,13 +370,13 @@ struct RtOracleOut {        // any pointer may be NULL; planes are W*H row-major
 };
 
 // Render rows [y0, y1) of a W x H frame with `spp` samples and `depth` levels.  threads <= 0 => OpenMP default.
-int rt_oracle_render(const uint32_t* materials, const uint8_t* minefield, const uint8_t* noise,
-                     const RtUniforms* u, int W, int H, int spp, int depth, int y0, int y1, int threads,
-                     RtOracleOut* out, RtCounters* counters) {
+int rt_oracle_render_region(const uint32_t* materials, const uint8_t* minefield, const uint8_t* noise,
+                            const RtUniforms* u, int region, int W, int H, int spp, int depth, int y0, int y1, int threads,
+                            RtOracleOut* out, RtCounters* counters) {
     if (!materials || !minefield || !noise || !u || !out || W <= 0 || H <= 0 || spp < 1 || depth < 0 ||
-        depth > RT_MAX_DEPTH || y0 < 0 || y1 > H || y0 > y1)
+        depth > RT_MAX_DEPTH || y0 < 0 || y1 > H || y0 > y1 || (region != 256 && region != 512 && region != 1024))
         return RT_ERR_INVALID_ARG;
-    Scene sc{materials, minefield, noise};
+    Scene sc{materials, minefield, noise, region};
     FrameConsts fc;
     fc.sunangle = sun_vector(u->sun_angle);       // raytrace.comp:317
     fc.sunlight = sun_color(fc.sunangle);         // raytrace.comp:318
@@ -600,6 +603,12 @@ int32_t rt_oracle_noise_level_texel(float noise_offset, int level) {
 }
 uint32_t rt_oracle_unorm(float x, float maxv) { return rtm_unorm(x, maxv); }
 uint32_t rt_oracle_f2u16(float x) { return rtm_f2u16(x); }
+
+// The reference's region size (ROOT_BLOCK_WIDTH = 256).
+int rt_oracle_render(const uint32_t* materials, const uint8_t* minefield, const uint8_t* noise, const RtUniforms* u, int W,
+                     int H, int spp, int depth, int y0, int y1, int threads, RtOracleOut* out, RtCounters* counters) {
+    return rt_oracle_render_region(materials, minefield, noise, u, kDefaultRegion, W, H, spp, depth, y0, y1, threads, out, counters);
+}
 
 // ---- single-function entry points for the known-answer tests ---------------------------------
 struct RtOracleHit {

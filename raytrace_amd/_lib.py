@@ -94,6 +94,7 @@ def host():
         lib.rth_material_get.argtypes = [C.c_int, P, P, P]
         lib.rth_pack_chunk.argtypes = [P, P, P]
         lib.rth_generate_region.argtypes = [C.c_uint64, P, P]
+        lib.rth_generate_region_r.argtypes = [C.c_uint64, C.c_int, P, P]
         lib.rth_region_from_ids.argtypes = [P, P, P]
         lib.rth_heightmap.argtypes = [C.c_long, C.c_long, C.c_uint64, P]
         lib.rth_copy_3d_u32.argtypes = [P] * 7

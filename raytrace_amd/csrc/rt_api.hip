@@ -19,8 +19,6 @@ namespace {
 
 thread_local std::string g_create_error = "";
 
-constexpr int kR = RT_ROOT_BLOCK_SIZE;
-constexpr size_t kVox = (size_t)kR * kR * kR;
 
 const size_t kBytesPerPixel[RT_BUF_COUNT] = {8, 2, 1, 4, 4, 4, 16, 16, 4, 4};
 
@@ -30,6 +28,9 @@ struct RtContext {
     RtConfig cfg{};
     int device = 0;
     int num_cus = 256;
+    int logr = 8;                       // log2 of the region edge
+    int region = RT_ROOT_BLOCK_SIZE;    // R
+    size_t vox = 0;                     // R^3
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err = "";
     bool has_world = false, has_noise = false;
@@ -165,6 +166,8 @@ rtd::Frame frame_of(const RtContext* c, const RtUniforms* u) {
     f.ntiles_local = c->ntiles_local;
     f.spp = c->cfg.spp; f.depth = c->cfg.depth;
     f.lr_zero = (u->lr[0] == 0 && u->lr[1] == 0 && u->lr[2] == 0) ? 1 : 0;
+    f.logr = c->logr;
+    f.region = (float)c->region;
     return f;
 }
 
@@ -186,7 +189,7 @@ struct LaunchTimer {
 
 int reflatten(RtContext* c) {
     RT_HIP(c, hipMemsetAsync(c->d_flag, 0, sizeof(uint32_t), c->stream));
-    RT_HIP(c, rtd::launch_flatten(c->d_mine_lin, c->d_mat_lin, c->d_mine_sw, c->d_mat_sw, c->d_coarse, c->d_flag, c->stream));
+    RT_HIP(c, rtd::launch_flatten(c->d_mine_lin, c->d_mat_lin, c->d_mine_sw, c->d_mat_sw, c->d_coarse, c->d_flag, c->logr, c->stream));
     uint32_t flag = 0;
     RT_HIP(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -254,7 +257,10 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (cfg->struct_size != sizeof(RtConfig)) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: RtConfig.struct_size mismatch");
     if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 16384 || cfg->height > 16384)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: width/height out of range");
-    if (cfg->region != RT_ROOT_BLOCK_SIZE) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: region must be 256");
+    if (cfg->region != 256 && cfg->region != 512 && cfg->region != 1024)
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: region must be 256 (the reference), 512 or 1024");
+    if (cfg->region != 256 && cfg->kernel == RT_KERNEL_WAVEFRONT)
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: the split wavefront baseline supports region 256 only");
     if (cfg->spp < 1 || cfg->spp > RT_NOISE_BYTES) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: spp out of range");
     if (cfg->depth < 0 || cfg->depth > RT_MAX_DEPTH) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: depth out of range");
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world)
@@ -277,6 +283,9 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
 
     c->cfg = *cfg;
     c->device = cfg->device;
+    c->region = cfg->region;
+    c->logr = cfg->region == 256 ? 8 : (cfg->region == 512 ? 9 : 10);
+    c->vox = (size_t)cfg->region * cfg->region * cfg->region;
     c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PERSISTENT : cfg->kernel;
     RT_HIP_CREATE(hipSetDevice(c->device));
     hipDeviceProp_t prop;
@@ -297,8 +306,8 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     c->plane_pixels = cfg->tile_world == 1 ? (size_t)cfg->width * cfg->height : (size_t)c->tile_capacity * 64;
 
     // scene
-    RT_HIP_CREATE(dev_alloc(c, &c->d_mine_lin, kVox)); RT_HIP_CREATE(dev_alloc(c, &c->d_mat_lin, kVox));
-    RT_HIP_CREATE(dev_alloc(c, &c->d_mine_sw, kVox)); RT_HIP_CREATE(dev_alloc(c, &c->d_mat_sw, kVox));
+    RT_HIP_CREATE(dev_alloc(c, &c->d_mine_lin, c->vox)); RT_HIP_CREATE(dev_alloc(c, &c->d_mat_lin, c->vox));
+    RT_HIP_CREATE(dev_alloc(c, &c->d_mine_sw, c->vox)); RT_HIP_CREATE(dev_alloc(c, &c->d_mat_sw, c->vox));
     RT_HIP_CREATE(dev_alloc(c, &c->d_coarse, (size_t)rtd::kCoarseWords));
     RT_HIP_CREATE(dev_alloc(c, &c->d_noise, (size_t)RT_NOISE_SIZE * RT_NOISE_SIZE));
     RT_HIP_CREATE(dev_alloc(c, &c->d_flag, 4));
@@ -410,8 +419,8 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
     if (!materials || !minefield) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_world: null pointer");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RT_HIP(ctx, hipMemcpy(ctx->d_mat_lin, materials, kVox * sizeof(uint32_t), hipMemcpyHostToDevice));
-    RT_HIP(ctx, hipMemcpy(ctx->d_mine_lin, minefield, kVox, hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_mat_lin, materials, ctx->vox * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_mine_lin, minefield, ctx->vox, hipMemcpyHostToDevice));
     ctx->has_world = false;
     int rc = reflatten(ctx);
     if (rc != RT_OK) return rc;
@@ -422,7 +431,8 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
 int rt_upload_slice(RtContext* ctx, int axis, int texel_offset, const uint32_t* materials, const uint8_t* minefield) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (!materials || !minefield) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_slice: null pointer");
-    if (axis < 0 || axis > 2 || texel_offset < 0 || texel_offset + RT_SLICE_SIZE > kR || texel_offset % RT_SLICE_SIZE != 0)
+    const size_t kR = (size_t)ctx->region;
+    if (axis < 0 || axis > 2 || texel_offset < 0 || texel_offset + RT_SLICE_SIZE > ctx->region || texel_offset % RT_SLICE_SIZE != 0)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_slice: bad axis or offset");
     if (!ctx->has_world) return fail(ctx, RT_ERR_NOT_READY, "rt_upload_slice: upload the full region first");
     RT_HIP(ctx, hipSetDevice(ctx->device));

@@ -14,20 +14,25 @@
 
 namespace rtd {
 
-constexpr int kR = RT_ROOT_BLOCK_SIZE;           // 256
-constexpr int kBricksPerAxis = kR / 4;           // 64
-constexpr int kBrickCount = kBricksPerAxis * kBricksPerAxis * kBricksPerAxis;  // 262144
-constexpr int kCoarseWords = kBrickCount / 8;    // 32768 u32 = 128 KiB: one nibble per 4^3 brick
-constexpr uint32_t kNibMixed = 15;               // brick holds differing values (or a value > 14): read the byte
+// Region edge R = 1 << logr.  The reference's ROOT_BLOCK_WIDTH is 256 (logr = 8); 512 and 1024 are the build's extension
+// (SURVEY 8d, config C5).  The nibble map always has 64^3 entries = 128 KiB (it has to fit LDS), so one entry covers a
+// cube of edge R/64: a 4^3 brick at R = 256, 8^3 at 512, 16^3 at 1024.
+constexpr int kCoarsePerAxis = 64;
+constexpr int kCoarseCount = kCoarsePerAxis * kCoarsePerAxis * kCoarsePerAxis;  // 262144
+constexpr int kCoarseWords = kCoarseCount / 8;   // 32768 u32 = 128 KiB: one nibble per coarse cube
+constexpr uint32_t kNibMixed = 15;               // cube holds differing values (or a value > 14): read the byte
 constexpr uint32_t kMaxStepValue = 30;           // minefield values above this are rejected at upload
 
-// Voxel (ix,iy,iz) in [0,256)^3 -> index into the brick-swizzled arrays: 64 consecutive entries per 4^3 brick,
-// so one 64-byte line of the minefield (256 B of the materials) is one brick.
-__device__ __forceinline__ uint32_t brick_of(int ix, int iy, int iz) {
-    return ((uint32_t)(iz >> 2) << 12) | ((uint32_t)(iy >> 2) << 6) | (uint32_t)(ix >> 2);
+// Voxel (ix,iy,iz) in [0,R)^3 -> index into the brick-swizzled arrays: 64 consecutive entries per 4^3 brick, so one
+// 64-byte line of the minefield (256 B of the materials) is one brick.  lb = logr - 2 = log2(bricks per axis).
+__device__ __forceinline__ uint32_t swizzled_index(int ix, int iy, int iz, int lb) {
+    const uint32_t brick = ((uint32_t)(iz >> 2) << (2 * lb)) | ((uint32_t)(iy >> 2) << lb) | (uint32_t)(ix >> 2);
+    return (brick << 6) | ((uint32_t)(iz & 3) << 4) | ((uint32_t)(iy & 3) << 2) | (uint32_t)(ix & 3);
 }
-__device__ __forceinline__ uint32_t swizzled_index(int ix, int iy, int iz) {
-    return (brick_of(ix, iy, iz) << 6) | ((uint32_t)(iz & 3) << 4) | ((uint32_t)(iy & 3) << 2) | (uint32_t)(ix & 3);
+// Voxel -> nibble-map entry: the top 6 bits of each coordinate.
+__device__ __forceinline__ uint32_t coarse_index(int ix, int iy, int iz, int logr) {
+    const int sh = logr - 6;
+    return ((uint32_t)(iz >> sh) << 12) | ((uint32_t)(iy >> sh) << 6) | (uint32_t)(ix >> sh);
 }
 
 struct Scene {
@@ -51,6 +56,8 @@ struct Frame {
     int ntiles_local;      // tiles this context renders
     int spp, depth;
     int lr_zero;           // lr == (0,0,0): enables the sky-first shortcut in the traversal loop
+    int logr;              // log2 of the region edge R (8, 9, 10)
+    float region;          // R as float (raytrace.comp:37 ROOT_BLOCK_WIDTH)
 };
 
 struct vec3 { float x, y, z; };
@@ -155,8 +162,8 @@ __device__ __forceinline__ void primary_ray(const Frame& f, int px, int py, vec3
     float sy = ((float)py / (float)f.height) * 2.0f - 1.0f;
     vec3 ray_start = ld3(f.origin);
     vec3 d = vnormalize(vadd(vadd(ld3(f.forward), vscale(ld3(f.right), sx)), vscale(ld3(f.up), sy)));
-    if (-ray_start.y > (float)kR / 2.0f) {
-        float space = -ray_start.y - ((float)kR / 2.0f);
+    if (-ray_start.y > f.region / 2.0f) {
+        float space = -ray_start.y - (f.region / 2.0f);
         ray_start = vadd(ray_start, vscale(d, space / d.y + 0.0001f));
     }
     *start = ray_start;
@@ -169,23 +176,21 @@ __device__ __forceinline__ vec3 albedo_of(uint32_t packed) {   // raytrace.comp:
 }
 
 // ---- texel addressing with the reference's border semantics ------------------------------------------------
-// mod(pos + 128, 256) per axis, then NEAREST + CLAMP_TO_BORDER (raytrace.comp:79,106,137; render_data.rs:90-101).
-// Returns false when any coordinate lands outside [0,256) or is NaN (border colour 0).
-__device__ __forceinline__ bool wrap_texel(vec3 pos, int* ix, int* iy, int* iz) {
-    const float W = (float)kR;
+// mod(pos + R/2, R) per axis, then NEAREST + CLAMP_TO_BORDER (raytrace.comp:79,106,137; render_data.rs:90-101).
+// Returns false when any coordinate lands outside [0,R) or is NaN (border colour 0).
+__device__ __forceinline__ bool wrap_texel(vec3 pos, float W, int* ix, int* iy, int* iz) {
     float cx = rtm_mod(pos.x + W / 2, W), cy = rtm_mod(pos.y + W / 2, W), cz = rtm_mod(pos.z + W / 2, W);
     bool ok = (cx >= 0.0f && cx < W) && (cy >= 0.0f && cy < W) && (cz >= 0.0f && cz < W);
     *ix = ok ? (int)cx : 0; *iy = ok ? (int)cy : 0; *iz = ok ? (int)cz : 0;
     return ok;
 }
-// textureLod(world, mod((pos+128)/256, 1.0), 0) — raytrace.comp:150-154 (normalised coordinates).
-__device__ __forceinline__ uint32_t fetch_material(const Scene& sc, vec3 pos) {
-    const float W = (float)kR;
+// textureLod(world, mod((pos+R/2)/R, 1.0), 0) — raytrace.comp:150-154 (normalised coordinates).
+__device__ __forceinline__ uint32_t fetch_material(const Scene& sc, vec3 pos, float W, int lb) {
     float ux = rtm_mod((pos.x + W / 2) / W, 1.0f) * W, uy = rtm_mod((pos.y + W / 2) / W, 1.0f) * W,
           uz = rtm_mod((pos.z + W / 2) / W, 1.0f) * W;
     bool ok = (ux >= 0.0f && ux < W) && (uy >= 0.0f && uy < W) && (uz >= 0.0f && uz < W);
     if (!ok) return 0u;
-    return sc.mat[swizzled_index((int)ux, (int)uy, (int)uz)];
+    return sc.mat[swizzled_index((int)ux, (int)uy, (int)uz, lb)];
 }
 
 // ---- one complete ray, generic form (any lr, byte minefield straight from memory) ---------------------------
@@ -198,10 +203,10 @@ struct Hit {
     uint32_t iterations, border, limit_exit;
 };
 
-__device__ __forceinline__ uint32_t fetch_step_global(const Scene& sc, vec3 pos, uint32_t* border) {
+__device__ __forceinline__ uint32_t fetch_step_global(const Scene& sc, vec3 pos, float W, int lb, uint32_t* border) {
     int ix, iy, iz;
-    if (!wrap_texel(pos, &ix, &iy, &iz)) { (*border)++; return 0u; }
-    return sc.mine[swizzled_index(ix, iy, iz)];
+    if (!wrap_texel(pos, W, &ix, &iy, &iz)) { (*border)++; return 0u; }
+    return sc.mine[swizzled_index(ix, iy, iz, lb)];
 }
 
 __device__ inline Hit trace_ray_generic(const Scene& sc, const Frame& f, vec3 origin, vec3 direction) {
@@ -211,8 +216,9 @@ __device__ inline Hit trace_ray_generic(const Scene& sc, const Frame& f, vec3 or
     vec3 len = v3(1.0f / rtm_abs(direction.x), 1.0f / rtm_abs(direction.y), 1.0f / rtm_abs(direction.z));   // :88
     uint32_t nx = direction.x > 0.0f ? 1u : 0u, ny = direction.y > 0.0f ? 3u : 2u, nz = direction.z > 0.0f ? 5u : 4u;
     vec3 muls = v3(direction.x > 0.0f ? -1.0f : 1.0f, direction.y > 0.0f ? -1.0f : 1.0f, direction.z > 0.0f ? -1.0f : 1.0f);
-    const float half = (float)kR / 2;
-    uint32_t step = fetch_step_global(sc, h.position, &h.border);                         // :106
+    const float half = f.region / 2;
+    const int lb = f.logr - 2;
+    uint32_t step = fetch_step_global(sc, h.position, f.region, lb, &h.border);           // :106
     uint32_t step_size = (1u << (step & 31u)) / 2u;                                        // :107
     bool done = false;
     for (uint32_t limit = RT_TRACE_LIMIT; limit > 0; limit--) {                            // :109-113
@@ -227,12 +233,12 @@ __device__ inline Hit trace_ray_generic(const Scene& sc, const Frame& f, vec3 or
         h.position = v3(rtm_fma(direction.x, t, h.position.x), rtm_fma(direction.y, t, h.position.y),
                         rtm_fma(direction.z, t, h.position.z));   // fused (rt_math.h contract)
         h.normal = n;
-        step = fetch_step_global(sc, h.position, &h.border);                               // :137
+        step = fetch_step_global(sc, h.position, f.region, lb, &h.border);                 // :137
         if (rtm_abs(h.position.x - f.lr[0]) >= half || rtm_abs(h.position.y - f.lr[1]) >= half ||
             rtm_abs(h.position.z - f.lr[2]) >= half) {                                      // :138-145
             h.air = true; done = true; break;
         } else if (step == 0u) {                                                            // :146-160
-            h.material = fetch_material(sc, h.position);
+            h.material = fetch_material(sc, h.position, f.region, lb);
             done = true; break;
         }
         step_size = (1u << (step & 31u)) / 2u;                                              // :161

@@ -24,31 +24,45 @@ namespace rtd {
 __global__ __launch_bounds__(256) void k_flatten_voxels(const uint8_t* __restrict__ mine_lin,
                                                         const uint32_t* __restrict__ mat_lin,
                                                         uint8_t* __restrict__ mine_sw, uint32_t* __restrict__ mat_sw,
-                                                        uint32_t* __restrict__ bad_value_flag) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly 256^3
+                                                        uint32_t* __restrict__ bad_value_flag, int logr) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly R^3 (< 2^31)
+    const int lb = logr - 2;
+    const uint32_t bmask = (1u << lb) - 1u;
     uint32_t brick = i >> 6, l = i & 63u;
-    uint32_t ix = ((brick & 63u) << 2) | (l & 3u);
-    uint32_t iy = (((brick >> 6) & 63u) << 2) | ((l >> 2) & 3u);
-    uint32_t iz = ((brick >> 12) << 2) | (l >> 4);
-    uint32_t src = (iz * kR + iy) * kR + ix;
+    uint32_t ix = ((brick & bmask) << 2) | (l & 3u);
+    uint32_t iy = (((brick >> lb) & bmask) << 2) | ((l >> 2) & 3u);
+    uint32_t iz = ((brick >> (2 * lb)) << 2) | (l >> 4);
+    size_t src = (((((size_t)iz << logr) + iy) << logr)) + ix;
     uint8_t v = mine_lin[src];
     if (v > kMaxStepValue) atomicOr(bad_value_flag, 1u);
     mine_sw[i] = v;
     mat_sw[i] = mat_lin[src];
 }
 
-// One thread per nibble-map word = 8 consecutive bricks = 512 contiguous bytes of the swizzled minefield.
-__global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict__ mine_sw, uint32_t* __restrict__ coarse) {
-    uint32_t w = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly kCoarseWords
-    const uint4* src = reinterpret_cast<const uint4*>(mine_sw) + (size_t)w * 32;
+// One thread per nibble-map word = 8 consecutive coarse cubes (x-adjacent).  A coarse cube has edge R/64 and is made of
+// (R/256)^3 4^3-bricks of 64 contiguous bytes each in the swizzled minefield.
+__global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict__ mine_sw, uint32_t* __restrict__ coarse, int logr) {
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly kCoarseWords
+    const int lb = logr - 2, sub = logr - 8;               // sub: log2(4^3-bricks per coarse cube edge)
+    const uint32_t nsub = 1u << sub;
     uint32_t word = 0;
-    for (int b = 0; b < 8; b++) {
-        uint4 a = src[b * 4 + 0], c = src[b * 4 + 1], d = src[b * 4 + 2], e = src[b * 4 + 3];
-        uint32_t first = a.x & 0xFFu, splat = first * 0x01010101u;
-        uint32_t diff = (a.x ^ splat) | (a.y ^ splat) | (a.z ^ splat) | (a.w ^ splat) | (c.x ^ splat) | (c.y ^ splat) |
-                        (c.z ^ splat) | (c.w ^ splat) | (d.x ^ splat) | (d.y ^ splat) | (d.z ^ splat) | (d.w ^ splat) |
-                        (e.x ^ splat) | (e.y ^ splat) | (e.z ^ splat) | (e.w ^ splat);
-        uint32_t nib = (diff == 0u && first < kNibMixed) ? first : kNibMixed;
+    for (uint32_t b = 0; b < 8u; b++) {
+        const uint32_t c = w * 8u + b;                     // coarse cube (cz, cy, cx), 6 bits each
+        const uint32_t cx = c & 63u, cy = (c >> 6) & 63u, cz = c >> 12;
+        uint32_t first = 0, diff = 0;
+        for (uint32_t bz = 0; bz < nsub; bz++)
+            for (uint32_t by = 0; by < nsub; by++)
+                for (uint32_t bx = 0; bx < nsub; bx++) {
+                    const uint32_t brick = (((((cz << sub) + bz) << lb) + ((cy << sub) + by)) << lb) + ((cx << sub) + bx);
+                    const uint4* src = reinterpret_cast<const uint4*>(mine_sw + ((size_t)brick << 6));
+                    const uint4 a = src[0], q = src[1], d = src[2], e = src[3];
+                    if ((bz | by | bx) == 0u) first = a.x & 0xFFu;
+                    const uint32_t splat = first * 0x01010101u;
+                    diff |= (a.x ^ splat) | (a.y ^ splat) | (a.z ^ splat) | (a.w ^ splat) | (q.x ^ splat) | (q.y ^ splat) |
+                            (q.z ^ splat) | (q.w ^ splat) | (d.x ^ splat) | (d.y ^ splat) | (d.z ^ splat) | (d.w ^ splat) |
+                            (e.x ^ splat) | (e.y ^ splat) | (e.z ^ splat) | (e.w ^ splat);
+                }
+        const uint32_t nib = (diff == 0u && first < kNibMixed) ? first : kNibMixed;
         word |= nib << (4 * b);
     }
     coarse[w] = word;
@@ -152,7 +166,8 @@ __global__ __launch_bounds__(1024, 4) void k_trace(Scene sc, Frame f, TraceArgs 
     const uint32_t nslots = MODE == 0 ? 0u : *a.qcount;
     const uint32_t total = MODE == 0 ? a.nprimary : 2u * nslots;
     const uint32_t threshold = a.refill_threshold;
-    const float half = (float)kR / 2;
+    const float half = f.region / 2;   // this kernel is built for the reference region size only (logr == 8)
+    const int lb = 6;
 
     bool active = false, pending = false, exhausted = false;
     // ray state
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(1024, 4) void k_trace(Scene sc, Frame f, TraceArgs 
                     if (kind == EXIT_AIR) {
                         c_sky++;
                         int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
-                        if (!wrap_texel(v3(px, py, pz), &tx, &ty, &tz)) c_border++;
+                        if (!wrap_texel(v3(px, py, pz), f.region, &tx, &ty, &tz)) c_border++;
                     } else if (kind == EXIT_LIMIT) c_limit++;
                     else c_hits++;
                     if (kind == EXIT_SPECIAL) c_border += 1u + (fresh_invalid ? 1u : 0u);
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(1024, 4) void k_trace(Scene sc, Frame f, TraceArgs 
                 } else {
                     uint32_t nrm = axis == 0 ? (dx > 0.0f ? 1u : 0u) : (axis == 1 ? (dy > 0.0f ? 3u : 2u) : (dz > 0.0f ? 5u : 4u));
                     uint32_t material = 0;
-                    if (kind == EXIT_HIT) material = fetch_material(sc, v3(px, py, pz));         // raytrace.comp:150-154
+                    if (kind == EXIT_HIT) material = fetch_material(sc, v3(px, py, pz), f.region, lb);         // raytrace.comp:150-154
                     if (kind == EXIT_SPECIAL) { px = py = pz = __builtin_nanf(""); }
                     const float off = 0.001f;                                                  // :166-180
                     if (nrm == 0) px += off; else if (nrm == 1) px -= off;
@@ -232,9 +247,9 @@ __global__ __launch_bounds__(1024, 4) void k_trace(Scene sc, Frame f, TraceArgs 
                     sgnz = dz > 0.0f ? 0x80000000u : 0u;
                     ux = px + half; uy = py + half; uz = pz + half;
                     int ix, iy, iz;
-                    valid = wrap_texel(o, &ix, &iy, &iz);                                        // :106 (Q6: no bounds test)
+                    valid = wrap_texel(o, f.region, &ix, &iy, &iz);                               // :106 (Q6: no bounds test)
                     fresh_invalid = !valid;
-                    vox = swizzled_index(ix, iy, iz);
+                    vox = swizzled_index(ix, iy, iz, lb);
                     n = 0; axis = 2; fresh = true; kind = EXIT_HIT;
                     if (dx != dx || dy != dy || dz != dz) { kind = EXIT_SPECIAL; n = 1; pending = true; }   // NaN direction
                     else active = true;
@@ -285,12 +300,12 @@ __global__ __launch_bounds__(1024, 4) void k_trace(Scene sc, Frame f, TraceArgs 
                     kind = EXIT_AIR; active = false; pending = true;
                 } else if (LRZ) {
                     const int ix = (int)ux & 255, iy = (int)uy & 255, iz = (int)uz & 255;
-                    vox = swizzled_index(ix, iy, iz);
+                    vox = swizzled_index(ix, iy, iz, lb);
                 } else {
                     int ix, iy, iz;
-                    valid = wrap_texel(v3(px, py, pz), &ix, &iy, &iz);
+                    valid = wrap_texel(v3(px, py, pz), f.region, &ix, &iy, &iz);
                     if (COUNT && !valid) c_border++;
-                    vox = swizzled_index(ix, iy, iz);
+                    vox = swizzled_index(ix, iy, iz, lb);
                 }
             }
         }
@@ -469,9 +484,10 @@ __global__ __launch_bounds__(256) void k_untile(const uint8_t* __restrict__ gath
 // Host-callable launchers (declared in rt_kernels.hpp)
 // =====================================================================================================
 hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
-                          uint32_t* coarse, uint32_t* bad_flag, hipStream_t st) {
-    hipLaunchKernelGGL(k_flatten_voxels, dim3((kR * kR * kR) / 256), dim3(256), 0, st, mine_lin, mat_lin, mine_sw, mat_sw, bad_flag);
-    hipLaunchKernelGGL(k_build_coarse, dim3(kCoarseWords / 256), dim3(256), 0, st, mine_sw, coarse);
+                          uint32_t* coarse, uint32_t* bad_flag, int logr, hipStream_t st) {
+    hipLaunchKernelGGL(k_flatten_voxels, dim3((1u << (3 * logr)) / 256u), dim3(256), 0, st, mine_lin, mat_lin, mine_sw, mat_sw,
+                       bad_flag, logr);
+    hipLaunchKernelGGL(k_build_coarse, dim3(kCoarseWords / 256), dim3(256), 0, st, mine_sw, coarse, logr);
     return hipGetLastError();
 }
 

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_build_sun_lut(Frame f, float4* __restri
 // halves the number of transition passes.
 struct RaySlot {
     float px, py, pz, dx, dy, dz, lx, ly, lz, ux, uy, uz;
-    uint32_t sgnx, sgny, sgnz, vox, n, axis, kind;
+    uint32_t sgnx, sgny, sgnz, vox, cidx, n, axis, kind;   // vox: swizzled voxel index; cidx: nibble-map entry (R > 256 only)
     bool tracing, valid, fresh, fresh_invalid;
 };
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_build_sky_lut(Frame f, float4* __restri
     dif_lut[4 * i + 3] = make_float4(sky.x, sky.y, sky.z, 0.0f);
 }
 
-template <bool LRZ, bool COUNT, bool CACHE>
+template <int LOGR, bool LRZ, bool COUNT, bool CACHE>
 __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes pl, PersistArgs a) {
     __shared__ uint32_t s_coarse[kCoarseWords];
     __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
@@ -187,13 +187,14 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * 1024u + threadIdx.x;
     const uint32_t threshold = a.threshold;
-    const float half = (float)kR / 2;
+    constexpr int R = 1 << LOGR, LB = LOGR - 2;
+    const float half = (float)R / 2;
     const vec3 sunangle = ld3(f.sunangle), sunlight = ld3(f.sunlight);
     const uint32_t D = (uint32_t)f.depth;
 
     RaySlot S, F;
     S.px = S.py = S.pz = S.dx = S.dy = S.lx = S.ly = S.lz = S.ux = S.uy = S.uz = 0.0f; S.dz = 1.0f;
-    S.sgnx = S.sgny = S.sgnz = S.vox = S.n = 0u; S.axis = 2u; S.kind = PX_HIT;
+    S.sgnx = S.sgny = S.sgnz = S.vox = S.cidx = S.n = 0u; S.axis = 2u; S.kind = PX_HIT;
     S.tracing = false; S.valid = true; S.fresh = false; S.fresh_invalid = false;
     F = S;
     // ---- path state ----
@@ -212,12 +213,12 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
 
     // ---- head of trace_ray (:83-107) ---------------------------------------------------------------------------
     // origin part, shared by the two rays of a level (same surface point): texel of the first fetch (:106, Q6)
-    auto arm = [&](RaySlot& r, vec3 ro, bool ok, uint32_t vox0) {   // needs r.d*, r.l* set
+    auto arm = [&](RaySlot& r, vec3 ro, bool ok, uint32_t vox0, uint32_t cidx0) {   // needs r.d*, r.l* set
         r.px = ro.x; r.py = ro.y; r.pz = ro.z;
         r.sgnx = r.dx > 0.0f ? 0x80000000u : 0u; r.sgny = r.dy > 0.0f ? 0x80000000u : 0u;           // :94-98
         r.sgnz = r.dz > 0.0f ? 0x80000000u : 0u;
         r.ux = ro.x + half; r.uy = ro.y + half; r.uz = ro.z + half;
-        r.valid = ok; r.fresh_invalid = !ok; r.vox = vox0;
+        r.valid = ok; r.fresh_invalid = !ok; r.vox = vox0; r.cidx = cidx0;
         r.n = 0; r.axis = 2; r.fresh = true; r.kind = PX_HIT;
         if (r.dx != r.dx || r.dy != r.dy || r.dz != r.dz) { r.kind = PX_SPECIAL; r.n = 1; r.tracing = false; }   // NaN direction
         else r.tracing = true;
@@ -263,13 +264,15 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             if (sky) {
                 r.kind = PX_AIR; r.tracing = false;
             } else if (LRZ) {
-                const int ix = (int)r.ux & 255, iy = (int)r.uy & 255, iz = (int)r.uz & 255;
-                r.vox = swizzled_index(ix, iy, iz);
+                const int ix = (int)r.ux & (R - 1), iy = (int)r.uy & (R - 1), iz = (int)r.uz & (R - 1);
+                r.vox = swizzled_index(ix, iy, iz, LB);
+                if (LOGR != 8) r.cidx = coarse_index(ix, iy, iz, LOGR);
             } else {
                 int ix, iy, iz;
-                r.valid = wrap_texel(v3(r.px, r.py, r.pz), &ix, &iy, &iz);
+                r.valid = wrap_texel(v3(r.px, r.py, r.pz), (float)R, &ix, &iy, &iz);
                 if (COUNT && !r.valid) c_border++;
-                r.vox = swizzled_index(ix, iy, iz);
+                r.vox = swizzled_index(ix, iy, iz, LB);
+                if (LOGR != 8) r.cidx = coarse_index(ix, iy, iz, LOGR);
             }
         }
     };
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
         if (r.kind == PX_AIR) {
             c_sky++;
             int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
-            if (!wrap_texel(v3(r.px, r.py, r.pz), &tx, &ty, &tz)) c_border++;
+            if (!wrap_texel(v3(r.px, r.py, r.pz), (float)R, &tx, &ty, &tz)) c_border++;
         } else if (r.kind == PX_LIMIT) c_limit++;
         else c_hits++;
         if (r.kind == PX_SPECIAL) c_border += 1u + (r.fresh_invalid ? 1u : 0u);
@@ -296,7 +299,8 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             const uint32_t target = n_busy > need ? n_busy - need : 0u;
             do {
                 // fetches of both slots first (:106 for a fresh ray, :137 otherwise), so their latencies overlap
-                const uint32_t bS = S.vox >> 6, bF = F.vox >> 6;
+                // nibble-map entry: at R = 256 a coarse cube IS the 4^3 brick, so the entry index is vox >> 6
+                const uint32_t bS = LOGR == 8 ? S.vox >> 6 : S.cidx, bF = LOGR == 8 ? F.vox >> 6 : F.cidx;
                 const uint32_t wS = s_coarse[bS >> 3], wF = s_coarse[bF >> 3];
                 uint32_t stS = (wS >> ((bS & 7u) << 2)) & 15u, stF = (wF >> ((bF & 7u) << 2)) & 15u;
                 const bool gS = S.tracing && stS == kNibMixed, gF = F.tracing && stF == kNibMixed;
@@ -448,16 +452,16 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             if (COUNT) { c_noise++; c_shadow++; c_dif++; }
             const vec3 ro = v3(sfx, sfy, sfz);
             int ix, iy, iz;
-            const bool ok = wrap_texel(ro, &ix, &iy, &iz);
-            const uint32_t vox0 = swizzled_index(ix, iy, iz);
+            const bool ok = wrap_texel(ro, (float)R, &ix, &iy, &iz);
+            const uint32_t vox0 = swizzled_index(ix, iy, iz, LB), cidx0 = coarse_index(ix, iy, iz, LOGR);
             const float4 sd = a.sun_lut[2u * (nvtex & 0xFFFFu)], sl = a.sun_lut[2u * (nvtex & 0xFFFFu) + 1u];
             S.dx = sd.x; S.dy = sd.y; S.dz = sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
-            arm(S, ro, ok, vox0);
+            arm(S, ro, ok, vox0, cidx0);
             const uint32_t di = 4u * ((snormal << 16) | (nvtex & 0xFFFFu));
             const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
             dif_entry = di;
             F.dx = d2.x; F.dy = d2.y; F.dz = d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
-            arm(F, ro, ok, vox0);
+            arm(F, ro, ok, vox0, cidx0);
             phase = PH_DIF;
         }
         // primary ray of the pixel (:296-315), CACHE=false only
@@ -466,9 +470,9 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             vec3 ro, rd;
             primary_ray(f, pix.px, pix.py, &ro, &rd);
             int ix, iy, iz;
-            const bool ok = wrap_texel(ro, &ix, &iy, &iz);
+            const bool ok = wrap_texel(ro, (float)R, &ix, &iy, &iz);
             set_dir(F, rd);
-            arm(F, ro, ok, swizzled_index(ix, iy, iz));
+            arm(F, ro, ok, swizzled_index(ix, iy, iz, LB), coarse_index(ix, iy, iz, LOGR));
             phase = PH_PRIMARY;
             if (COUNT) c_prim++;
         }
@@ -546,11 +550,11 @@ hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, con
     return hipGetLastError();
 }
 
-hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
-                          int nworkgroups, hipStream_t st) {
-    dim3 grid(nworkgroups), block(1024);
+template <int LOGR>
+static void launch_persist_logr(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
+                                dim3 grid, dim3 block, hipStream_t st) {
     const bool lrz = f.lr_zero != 0;
-#define RT_LAUNCH_PERSIST(L, C, K) hipLaunchKernelGGL((k_persist<L, C, K>), grid, block, 0, st, sc, f, pl, a)
+#define RT_LAUNCH_PERSIST(L, C, K) hipLaunchKernelGGL((k_persist<LOGR, L, C, K>), grid, block, 0, st, sc, f, pl, a)
     if (lrz) {
         if (count) { if (cache) RT_LAUNCH_PERSIST(true, true, true); else RT_LAUNCH_PERSIST(true, true, false); }
         else       { if (cache) RT_LAUNCH_PERSIST(true, false, true); else RT_LAUNCH_PERSIST(true, false, false); }
@@ -559,6 +563,15 @@ hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, con
         else       { if (cache) RT_LAUNCH_PERSIST(false, false, true); else RT_LAUNCH_PERSIST(false, false, false); }
     }
 #undef RT_LAUNCH_PERSIST
+}
+
+hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
+                          int nworkgroups, hipStream_t st) {
+    dim3 grid(nworkgroups), block(1024);
+    if (f.logr == 8) launch_persist_logr<8>(sc, f, pl, a, count, cache, grid, block, st);
+    else if (f.logr == 9) launch_persist_logr<9>(sc, f, pl, a, count, cache, grid, block, st);
+    else if (f.logr == 10) launch_persist_logr<10>(sc, f, pl, a, count, cache, grid, block, st);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -53,6 +53,12 @@ int rth_generate_region(uint64_t seed, uint32_t* materials, uint8_t* minefield) 
     return RT_OK;
 }
 
+int rth_generate_region_r(uint64_t seed, int region, uint32_t* materials, uint8_t* minefield) {
+    if (!materials || !minefield || (region != 256 && region != 512 && region != 1024)) return RT_ERR_INVALID_ARG;
+    world::assemble_region_procedural(seed, materials, minefield, region);
+    return RT_OK;
+}
+
 int rth_region_from_ids(const uint8_t* ids, uint32_t* materials, uint8_t* minefield) {
     if (!ids || !materials || !minefield) return RT_ERR_INVALID_ARG;
     world::assemble_region_from_ids(ids, materials, minefield);

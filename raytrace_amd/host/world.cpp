@@ -248,25 +248,25 @@ template void fill_slice_3d_auto_clip<uint8_t>(uint8_t, uint8_t*, int, Off3, Dim
 
 // ---- region assembly (render_data.rs:203-249) -------------------------------------------------------------
 namespace {
-void place_chunk(const PackedChunkData& pc, int cx, int cy, int cz, uint32_t* materials, uint8_t* minefield) {
+void place_chunk(const PackedChunkData& pc, int cx, int cy, int cz, uint32_t* materials, uint8_t* minefield, int region = kRegion) {
     Off3 at{(long)cx * kChunk, (long)cy * kChunk, (long)cz * kChunk};  // scale_coord_3d(&chunk_coord, CHUNK_SIZE)
-    copy_3d_auto_clip(pc.materials.data(), kChunk, at, materials, kRegion);
-    copy_3d_auto_clip(pc.minefield.data(), kChunk, at, minefield, kRegion);
+    copy_3d_auto_clip(pc.materials.data(), kChunk, at, materials, region);
+    copy_3d_auto_clip(pc.minefield.data(), kChunk, at, minefield, region);
 }
 }  // namespace
 
-void assemble_region_procedural(uint64_t seed, uint32_t* materials, uint8_t* minefield) {
-    const int half = kRegionChunks / 2;
+void assemble_region_procedural(uint64_t seed, uint32_t* materials, uint8_t* minefield, int region) {
+    const int nchunks = region / kChunk, half = nchunks / 2;
     UnpackedChunkData uc;
     PackedChunkData pc;
     Heightmap hm;
-    for (int cy = 0; cy < kRegionChunks; cy++)
-        for (int cx = 0; cx < kRegionChunks; cx++) {
+    for (int cy = 0; cy < nchunks; cy++)
+        for (int cx = 0; cx < nchunks; cx++) {
             generate_heightmap(hm, cx - half, cy - half, seed);
-            for (int cz = 0; cz < kRegionChunks; cz++) {
+            for (int cz = 0; cz < nchunks; cz++) {
                 generate_chunk(uc, cx - half, cy - half, cz - half, hm, seed);
                 uc.pack_into(pc);
-                place_chunk(pc, cx, cy, cz, materials, minefield);
+                place_chunk(pc, cx, cy, cz, materials, minefield, region);
             }
         }
 }

@@ -70,7 +70,9 @@ double mountain_noise2(double x, double y, uint64_t seed);                      
 
 // Region assembly — RenderData::make_world_upload_buffers (render_data.rs:203-249): region chunk c in [0,4)^3 holds
 // world chunk c-2 and lands at texel offset c*64 (copy_materials/copy_minefield, chunk.rs:66-94).
-void assemble_region_procedural(uint64_t seed, uint32_t* materials, uint8_t* minefield);
+// `region` = edge R of the target arrays: 256 in the reference (ROOT_BLOCK_SIZE); 512 / 1024 are the build's extension
+// (R/64 chunks per axis, centred on the origin like the reference's 4).
+void assemble_region_procedural(uint64_t seed, uint32_t* materials, uint8_t* minefield, int region = kRegion);
 // Same assembly for caller-provided voxel ids (u8[256^3], texel space, x fastest).
 void assemble_region_from_ids(const uint8_t* ids, uint32_t* materials, uint8_t* minefield);
 

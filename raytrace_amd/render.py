@@ -23,10 +23,11 @@ class RtError(RuntimeError):
         self.code = code
 
 
-def make_config(width, height, spp=1, depth=2, device=0, tile_rank=0, tile_world=1, kernel=RT_KERNEL_DEFAULT, flags=0):
+def make_config(width, height, spp=1, depth=2, device=0, tile_rank=0, tile_world=1, kernel=RT_KERNEL_DEFAULT, flags=0,
+                region=256):
     cfg = RtConfig()
     cfg.struct_size = C.sizeof(RtConfig)
-    cfg.width, cfg.height, cfg.region = int(width), int(height), 256
+    cfg.width, cfg.height, cfg.region = int(width), int(height), int(region)
     cfg.spp, cfg.depth, cfg.device = int(spp), int(depth), int(device)
     cfg.tile_rank, cfg.tile_world = int(tile_rank), int(tile_world)
     cfg.kernel, cfg.flags = int(kernel), int(flags)
@@ -84,15 +85,17 @@ class Context:
     def upload_world(self, materials, minefield):
         materials = np.ascontiguousarray(materials, dtype=np.uint32).reshape(-1)
         minefield = np.ascontiguousarray(minefield, dtype=np.uint8).reshape(-1)
-        if materials.size != 256 ** 3 or minefield.size != 256 ** 3:
-            raise ValueError("world arrays must hold 256^3 voxels")
+        n = (self.cfg.region if self.cfg is not None else 256) ** 3
+        if materials.size != n or minefield.size != n:
+            raise ValueError("world arrays must hold region^3 voxels")
         self._check(self._lib.rt_upload_world(self._h, _p(materials), _p(minefield)))
 
     def upload_slice(self, axis, texel_offset, materials, minefield):
         materials = np.ascontiguousarray(materials, dtype=np.uint32).reshape(-1)
         minefield = np.ascontiguousarray(minefield, dtype=np.uint8).reshape(-1)
-        if materials.size != 16 * 256 * 256 or minefield.size != 16 * 256 * 256:
-            raise ValueError("slice arrays must hold 16*256*256 voxels")
+        n = 16 * (self.cfg.region if self.cfg is not None else 256) ** 2
+        if materials.size != n or minefield.size != n:
+            raise ValueError("slice arrays must hold 16*region*region voxels")
         self._check(self._lib.rt_upload_slice(self._h, int(axis), int(texel_offset), _p(materials), _p(minefield)))
 
     def upload_noise(self, rgba8):

@@ -50,14 +50,16 @@ def pack_chunk(ids):
     return mats.reshape(64, 64, 64), mine.reshape(64, 64, 64)
 
 
-def generate_region(seed=DEFAULT_SEED):
-    """Procedural 256^3 region (render_data.rs:203-249 assembly over the deterministic generator).
-    Returns (materials u32[256,256,256], minefield u8[256,256,256]) indexed [z,y,x], texel = world + 128."""
-    mats = np.zeros(REGION_VOLUME, dtype=np.uint32)
-    mine = np.zeros(REGION_VOLUME, dtype=np.uint8)
-    rc = _lib.host().rth_generate_region(C.c_uint64(int(seed)), _p(mats), _p(mine))
+def generate_region(seed=DEFAULT_SEED, region=256):
+    """Procedural R^3 region (render_data.rs:203-249 assembly over the deterministic generator; R = 256 in the reference,
+    512 / 1024 are the build's extension).  Returns (materials u32[R,R,R], minefield u8[R,R,R]) indexed [z,y,x],
+    texel = world + R/2."""
+    n = int(region) ** 3
+    mats = np.zeros(n, dtype=np.uint32)
+    mine = np.zeros(n, dtype=np.uint8)
+    rc = _lib.host().rth_generate_region_r(C.c_uint64(int(seed)), int(region), _p(mats), _p(mine))
     assert rc == 0
-    return mats.reshape(256, 256, 256), mine.reshape(256, 256, 256)
+    return mats.reshape(region, region, region), mine.reshape(region, region, region)
 
 
 def region_from_ids(ids):

@@ -334,3 +334,61 @@ def test_bench_two_rank_rehearsal_assembles_the_same_frame():
                     "data", "config", "roofline", "cpu_baseline"):
             assert key in j
         assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+
+
+@pytest.fixture(scope="module")
+def region512(native_built):
+    return world.generate_region(world.DEFAULT_SEED, region=512)
+
+
+@pytest.mark.parametrize("kernel,flags", [(abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS),
+                                          (abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_CACHE_PRIMARY),
+                                          (abi.RT_KERNEL_MEGA, abi.RT_FLAG_COUNTERS)])
+@pytest.mark.parametrize("pose", [
+    dict(origin=(-60.0, -256.0, 110.0), heading=np.pi / 2, pitch=-0.05, sun=0.0, lr=(0, 0, 0)),
+    dict(origin=(200.0, 180.0, 90.0), heading=-2.3, pitch=-0.2, sun=0.8, lr=(0, 0, 0)),
+    dict(origin=(-30.0, -200.0, 100.0), heading=1.4, pitch=0.0, sun=0.2, lr=(32, -16, 0)),
+])
+def test_region_512_matches_oracle(region512, blue_noise, kernel, flags, pose):
+    """Region-size extension (config C5 family): ROOT_BLOCK_WIDTH = 512, nibble map over 8^3 cubes."""
+    mats, mine = region512
+    u = po.camera_uniforms(pose["origin"], pose["heading"], pose["pitch"], pose["sun"], 11, pose["lr"])
+    W, H, spp, depth = 104, 72, 2, 3
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth, region=512)
+    cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=kernel, flags=flags, region=512)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(u)
+        ctx.sync()
+        gpu = ctx.readback_all()
+        gcn = ctx.counters()
+    if flags & abi.RT_FLAG_CACHE_PRIMARY:
+        _compare(gpu, cpu)
+    else:
+        _compare(gpu, cpu, gcn, ccn)
+
+
+def test_region_size_validation(native_built):
+    with pytest.raises(render.RtError):
+        render.Context(render.make_config(64, 64, region=300))
+    with pytest.raises(render.RtError):
+        render.Context(render.make_config(64, 64, region=512, kernel=abi.RT_KERNEL_WAVEFRONT))
+
+
+@pytest.mark.skipif(not os.environ.get("RT_TEST_REGION_1024"), reason="5 GiB scene; set RT_TEST_REGION_1024=1 to run")
+def test_region_1024_matches_oracle(blue_noise, native_built):
+    """Config C5's scene size: 1024^3 (1 GiB minefield + 4 GiB materials — larger than the 256 MiB Infinity Cache)."""
+    mats, mine = world.generate_region(world.DEFAULT_SEED, region=1024)
+    u = po.camera_uniforms((-120.0, -512.0, 400.0), np.pi / 2, -0.3, 0.0, 1)
+    W, H, spp, depth = 96, 64, 1, 2
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth, region=1024)
+    cfg = render.make_config(W, H, spp=spp, depth=depth, flags=abi.RT_FLAG_COUNTERS, region=1024)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(u)
+        ctx.sync()
+        gpu = ctx.readback_all()
+        gcn = ctx.counters()
+    _compare(gpu, cpu, gcn, ccn)
