@@ -94,8 +94,14 @@ def main():
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     if os.environ.get("RT_BENCH_SINGLE_DEVICE"):
         local_rank = 0
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1 runs the N>1 code path (process group, gather, reductions) with a single rank: the only way
+    # to exercise the RCCL calls on a one-GPU box (tests/test_gpu_parity.py::test_bench_rccl_path_single_rank)
+    dist_on = world > 1 or bool(os.environ.get("RT_BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -156,7 +162,7 @@ def main():
                   abi.RT_BUF_EMISSION_RGBA8, abi.RT_BUF_FOG_RGBA8]
     bpp = {abi.RT_BUF_LIGHTING_RGBA16: 8, abi.RT_BUF_DEPTH_R16UI: 2, abi.RT_BUF_NORMAL_R8UI: 1, abi.RT_BUF_ALBEDO_RGBA8: 4,
            abi.RT_BUF_EMISSION_RGBA8: 4, abi.RT_BUF_FOG_RGBA8: 4}
-    if world > 1:
+    if dist_on:
         # one collective per frame: the six planes are one contiguous block on every rank (rt_gbuffer_ptr)
         gbytes = ctx.gbuffer_bytes()
         local_view = torch.as_tensor(_DevArray(ctx.gbuffer_ptr(), gbytes), device=dev)
@@ -165,7 +171,7 @@ def main():
 
     def step():
         ctx.draw_frame(u)
-        if world > 1:
+        if dist_on:
             if backend == "nccl":
                 if rank == 0:
                     dist.gather(local_view, list(gathered.chunk(world)), dst=0)
@@ -179,11 +185,15 @@ def main():
                     gathered.copy_(torch.cat(parts))
                 else:
                     dist.gather(host, None, dst=0)
-            if rank == 0:
+            if rank == 0 and world > 1:
                 ctx.untile_gbuffer(gathered.data_ptr(), world, [frames[b].data_ptr() for b in gather_ids])
+            elif rank == 0:   # forced single-rank run: the block already holds row-major planes
+                for b in gather_ids:
+                    off = ctx.gbuffer_offset(b)
+                    frames[b].copy_(gathered[off:off + frames[b].numel()])
 
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -207,7 +217,7 @@ def main():
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     sums = torch.tensor([float(rays_local), float(trace_bytes_local), float(balg_local), float(ref_equiv_rays_local)],
                         dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     elapsed = float(t_all.item())
@@ -219,7 +229,7 @@ def main():
         import hashlib
         hsh = hashlib.sha256()
         for b in gather_ids:
-            if world > 1:
+            if dist_on:
                 hsh.update(frames[b].cpu().numpy().tobytes())
             else:
                 hsh.update(ctx.readback(b).tobytes())
@@ -258,7 +268,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ctx.destroy()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -260,7 +260,9 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             r.n++;
             r.ux = r.px + half; r.uy = r.py + half; r.uz = r.pz + half;
             // sky test (:138-145), then the address of the next fetch
-            const bool sky = rtm_abs(r.px - f.lr[0]) >= half || rtm_abs(r.py - f.lr[1]) >= half || rtm_abs(r.pz - f.lr[2]) >= half;
+            // with lr = 0 the subtraction p - lr is the identity
+            const bool sky = LRZ ? (rtm_abs(r.px) >= half || rtm_abs(r.py) >= half || rtm_abs(r.pz) >= half)
+                                 : (rtm_abs(r.px - f.lr[0]) >= half || rtm_abs(r.py - f.lr[1]) >= half || rtm_abs(r.pz - f.lr[2]) >= half);
             if (sky) {
                 r.kind = PX_AIR; r.tracing = false;
             } else if (LRZ) {

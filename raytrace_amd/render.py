@@ -152,6 +152,10 @@ class Context:
     def gbuffer_bytes(self):
         return int(self._lib.rt_gbuffer_bytes(self._h))
 
+    def gbuffer_offset(self, buffer_id):
+        """Byte offset of a reference-format plane inside the contiguous G-buffer block."""
+        return int(self._lib.rt_gbuffer_offset(self._h, int(buffer_id)))
+
     def untile_gbuffer(self, gathered_dev_ptr, world, frame_dev_ptrs):
         """Scatter `world` gathered G-buffer blocks into six row-major planes (device pointers, None to skip)."""
         arr = (C.c_void_p * 6)(*[C.c_void_p(p) if p else None for p in frame_dev_ptrs])

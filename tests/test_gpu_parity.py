@@ -336,6 +336,27 @@ def test_bench_two_rank_rehearsal_assembles_the_same_frame():
         assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
 
 
+def test_bench_rccl_path_single_rank():
+    """bench.py's N>1 code path over RCCL ("nccl" backend: process group bound to the device, gather of the context's
+    G-buffer block, MAX/SUM reductions, barrier) with a single rank — what a one-GPU box can run of it.  Same frame hash
+    as the plain run."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    common = ["--width", "200", "--height", "120", "--spp", "4", "--depth", "3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("RT_BENCH_BACKEND", None)
+    forced = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    j2 = json.loads([l for l in forced.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["config"]["frame_sha256_16"] == j2["config"]["frame_sha256_16"]
+    assert j1["config"]["rays_per_frame"] == j2["config"]["rays_per_frame"]
+
+
 @pytest.fixture(scope="module")
 def region512(native_built):
     return world.generate_region(world.DEFAULT_SEED, region=512)
