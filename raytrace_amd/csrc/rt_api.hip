@@ -49,7 +49,7 @@ struct RtContext {
     void* gbuffer = nullptr;            // planes 0..5 back to back (256-byte aligned each)
     size_t gbuffer_offset[6] = {};
     size_t gbuffer_bytes = 0;
-    void* lighting_pong = nullptr;   // lighting_pong_buffer, render_data.rs:178-182
+    void* denoise_work[2] = {nullptr, nullptr};   // ping/pong working planes of the denoise passes (16 B/pixel), allocated on first use
 
     // wavefront pipeline state
     int kernel = RT_KERNEL_PERSISTENT;
@@ -335,7 +335,6 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         }
     }
 
-    { uint8_t* p = nullptr; RT_HIP_CREATE(dev_alloc(c, &p, c->plane_pixels * 8)); c->lighting_pong = p; }
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD_SUN")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold_sun = (uint32_t)v; }
@@ -575,13 +574,22 @@ int rt_denoise(RtContext* ctx, int faithful) {
     if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_denoise: no frame drawn yet");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int sizes[6] = {1, 2, 4, 8, 8, 16};                         // pipeline.rs:103
-    void* ping = ctx->planes[RT_BUF_LIGHTING_RGBA16];
-    void* pong = ctx->lighting_pong;
-    for (int pass = 0; pass < 6; pass++) {
-        const bool odd = pass % 2 == 1;                               // pipeline.rs:104-108: ping set on even, pong set on odd
+    for (int i = 0; i < 2; i++)
+        if (!ctx->denoise_work[i]) { uint4* p = nullptr; RT_HIP(ctx, dev_alloc(ctx, &p, ctx->plane_pixels)); ctx->denoise_work[i] = p; }
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    void* lighting = ctx->planes[RT_BUF_LIGHTING_RGBA16];
+    {
         LaunchTimer t(ctx, 1);
-        RT_HIP(ctx, rtd::launch_denoise(odd ? pong : ping, ctx->planes[RT_BUF_DEPTH_R16UI], ctx->planes[RT_BUF_NORMAL_R8UI],
-                                        ctx->cfg.width, ctx->cfg.height, sizes[pass], odd && faithful != 0, odd ? ping : pong, ctx->stream));
+        RT_HIP(ctx, rtd::launch_denoise_prepare(lighting, ctx->planes[RT_BUF_DEPTH_R16UI], ctx->planes[RT_BUF_NORMAL_R8UI], W, H,
+                                                ctx->denoise_work[0], ctx->stream));
+    }
+    for (int pass = 0; pass < 6; pass++) {
+        // pipeline.rs:104-108: the ping descriptor set on even dispatches, the pong set (normal/depth bindings swapped,
+        // descriptor_sets.rs:38-39) on odd ones; the sixth dispatch writes the lighting image finalize.comp reads
+        const bool odd = pass % 2 == 1;
+        LaunchTimer t(ctx, 1);
+        RT_HIP(ctx, rtd::launch_denoise(ctx->denoise_work[pass & 1], W, H, sizes[pass], odd && faithful != 0, pass == 5,
+                                        ctx->denoise_work[(pass & 1) ^ 1], lighting, ctx->stream));
     }
     return RT_OK;
 }

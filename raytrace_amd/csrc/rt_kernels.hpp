@@ -98,8 +98,10 @@ hipError_t launch_untile(const void* gathered, void* frame, int world, int capac
                          int height, int bpp, hipStream_t st);
 
 // rt_post.hip: the reference's post passes
-hipError_t launch_denoise(const void* lighting_in, const void* depth, const void* normal, int W, int H, int size, bool swapped,
-                          void* lighting_out, hipStream_t st);
+hipError_t launch_denoise_prepare(const void* lighting, const void* depth, const void* normal, int W, int H, void* work,
+                                  hipStream_t st);
+hipError_t launch_denoise(const void* work_in, int W, int H, int size, bool swapped, bool last, void* work_out, void* lighting,
+                          hipStream_t st);
 hipError_t launch_finalize(const void* albedo, const void* emission, const void* fog, const void* lighting, const void* depth,
                            const uint32_t* noise, int W, int H, void* out_bgra8, hipStream_t st);
 

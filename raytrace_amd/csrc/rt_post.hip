@@ -10,7 +10,7 @@ namespace rtd {
 
 struct DenoiseTap { int dx, dy; float w; };
 // the 36 SAMPLE(...) lines of bilateral_denoise.comp:45-88, in source order (the sum order is part of the result)
-__constant__ DenoiseTap kDenoiseTaps[36] = {
+constexpr DenoiseTap kDenoiseTaps[36] = {
     {0, 1, 0.092566f}, {0, -1, 0.092566f}, {1, 0, 0.092566f}, {-1, 0, 0.092566f},
     {1, 1, 0.058434f}, {-1, 1, 0.058434f}, {-1, -1, 0.058434f}, {1, -1, 0.058434f},
     {2, 0, 0.023205f}, {-2, 0, 0.023205f}, {0, 2, 0.023205f}, {0, -2, 0.023205f},
@@ -21,47 +21,75 @@ __constant__ DenoiseTap kDenoiseTaps[36] = {
     {3, 1, 0.001445f}, {-3, 1, 0.001445f}, {-3, -1, 0.001445f}, {3, -1, 0.001445f},
     {1, 3, 0.001445f}, {-1, 3, 0.001445f}, {-1, -3, 0.001445f}, {1, -3, 0.001445f}};
 
+// The six dispatches work on a 16-byte working pixel: the three lighting channels as the floats the shader's imageLoad
+// returns (u16 / 65535, bilateral_denoise.comp:27,41) and one word of guide bits, depth | normal << 16 | computed << 24.
+// A pixel is read by up to 37 taps per pass, so converting it once where it is produced (instead of once per tap)
+// removes three IEEE divisions and two loads from every tap; the values are the same bit for bit.
+constexpr uint32_t kDnComputed = 1u << 24;   // the pixel went through the filter branch at least once (alpha = 1.0, :89)
+
+__global__ __launch_bounds__(256) void k_denoise_prepare(const ushort4* __restrict__ lin, const uint16_t* __restrict__ depth,
+                                                         const uint8_t* __restrict__ normal, uint32_t n, uint4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const ushort4 l = lin[i];
+    uint4 o;
+    o.x = __builtin_bit_cast(uint32_t, (float)l.x / 65535.0f);
+    o.y = __builtin_bit_cast(uint32_t, (float)l.y / 65535.0f);
+    o.z = __builtin_bit_cast(uint32_t, (float)l.z / 65535.0f);
+    o.w = (uint32_t)depth[i] | (uint32_t)normal[i] << 16;
+    out[i] = o;
+}
+
 // One dispatch of bilateral_denoise.comp.  SWAPPED = the "pong" descriptor set, on which the reference binds the normal
 // image to the shader's depth binding and the depth image to its normal binding (descriptor_sets.rs:38-39 vs :31-32).
-template <bool SWAPPED>
-__global__ __launch_bounds__(256) void k_denoise_pass(const ushort4* __restrict__ lin, const uint16_t* __restrict__ depth,
-                                                      const uint8_t* __restrict__ normal, int W, int H, int size,
-                                                      ushort4* __restrict__ lout) {
+// LAST = the sixth dispatch: also stores the RGBA16 lighting image the later passes read.
+template <bool SWAPPED, bool LAST>
+__global__ __launch_bounds__(256) void k_denoise_pass(const uint4* __restrict__ in, int W, int H, int size, uint4* __restrict__ out,
+                                                      ushort4* __restrict__ lighting) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const size_t c = (size_t)y * W + x;
-    auto depth_binding = [&](size_t i) -> uint32_t { return SWAPPED ? (uint32_t)normal[i] : (uint32_t)depth[i]; };
-    auto normal_binding = [&](size_t i) -> uint32_t { return SWAPPED ? (uint32_t)depth[i] : (uint32_t)normal[i]; };
-    const float center_distance = (float)depth_binding(c) / 256.0f;                                  // :36
-    const uint32_t center_normal = normal_binding(c);                                                // :37
-    const ushort4 lc = lin[c];
+    auto depth_binding = [](uint32_t g) -> uint32_t { return SWAPPED ? (g >> 16 & 0xFFu) : (g & 0xFFFFu); };
+    auto normal_binding = [](uint32_t g) -> uint32_t { return SWAPPED ? (g & 0xFFFFu) : (g >> 16 & 0xFFu); };
+    uint4 pc = in[c];
+    const float center_distance = (float)depth_binding(pc.w) / 256.0f;                               // :36
+    const uint32_t center_normal = normal_binding(pc.w);                                             // :37
     if (center_normal < 16u) {                                                                       // :39
         float total_weight = 0.146634f;                                                              // :40
-        float sr = ((float)lc.x / 65535.0f) * total_weight, sg = ((float)lc.y / 65535.0f) * total_weight,
-              sb = ((float)lc.z / 65535.0f) * total_weight;                                          // :41
-#pragma unroll 4
+        float sr = __builtin_bit_cast(float, pc.x) * total_weight, sg = __builtin_bit_cast(float, pc.y) * total_weight,
+              sb = __builtin_bit_cast(float, pc.z) * total_weight;                                   // :41
+#pragma unroll
         for (int t = 0; t < 36; t++) {                                                               // SAMPLE, :23-33
             int px = x + kDenoiseTaps[t].dx * size, py = y + kDenoiseTaps[t].dy * size;             // sampleAt, :14-21
             px = px < 0 ? 0 : (px >= W ? W - 1 : px);
             py = py < 0 ? 0 : (py >= H ? H - 1 : py);
-            const size_t i = (size_t)py * W + px;
-            const float dist = (float)depth_binding(i) / 256.0f;
+            const uint4 l = in[(size_t)py * W + px];
+            const float dist = (float)depth_binding(l.w) / 256.0f;
             const float distance_difference = 4.0f * rtm_abs(center_distance - dist);
-            const float normal_difference = normal_binding(i) == center_normal ? 0.0f : 10.0f;
+            const float normal_difference = normal_binding(l.w) == center_normal ? 0.0f : 10.0f;
             const float weight = kDenoiseTaps[t].w / (distance_difference + normal_difference + 1.0f);
             total_weight += weight;
-            const ushort4 l = lin[i];
-            sr = rtm_fma((float)l.x / 65535.0f, weight, sr);
-            sg = rtm_fma((float)l.y / 65535.0f, weight, sg);
-            sb = rtm_fma((float)l.z / 65535.0f, weight, sb);
+            sr = rtm_fma(__builtin_bit_cast(float, l.x), weight, sr);
+            sg = rtm_fma(__builtin_bit_cast(float, l.y), weight, sg);
+            sb = rtm_fma(__builtin_bit_cast(float, l.z), weight, sb);
         }
+        const uint32_t qr = rtm_unorm(sr / total_weight, 65535.0f), qg = rtm_unorm(sg / total_weight, 65535.0f),
+                       qb = rtm_unorm(sb / total_weight, 65535.0f);                                  // imageStore to RGBA16_UNORM, :89
+        pc.x = __builtin_bit_cast(uint32_t, (float)qr / 65535.0f);
+        pc.y = __builtin_bit_cast(uint32_t, (float)qg / 65535.0f);
+        pc.z = __builtin_bit_cast(uint32_t, (float)qb / 65535.0f);
+        pc.w |= kDnComputed;
+        if (LAST) { ushort4 o; o.x = (uint16_t)qr; o.y = (uint16_t)qg; o.z = (uint16_t)qb; o.w = 65535; lighting[c] = o; }
+    } else if (LAST) {                                                                               // :91 (copy)
+        // u16 -> float -> u16 is the identity (q/65535 rounds back to q); alpha of a never-filtered pixel is the original one
         ushort4 o;
-        o.x = (uint16_t)rtm_unorm(sr / total_weight, 65535.0f); o.y = (uint16_t)rtm_unorm(sg / total_weight, 65535.0f);
-        o.z = (uint16_t)rtm_unorm(sb / total_weight, 65535.0f); o.w = 65535;                         // :89
-        lout[c] = o;
-    } else {
-        lout[c] = lc;                                                                                // :91
+        o.x = (uint16_t)rtm_unorm(__builtin_bit_cast(float, pc.x), 65535.0f);
+        o.y = (uint16_t)rtm_unorm(__builtin_bit_cast(float, pc.y), 65535.0f);
+        o.z = (uint16_t)rtm_unorm(__builtin_bit_cast(float, pc.z), 65535.0f);
+        o.w = (pc.w & kDnComputed) ? (uint16_t)65535 : lighting[c].w;
+        lighting[c] = o;
     }
+    if (!LAST) out[c] = pc;
 }
 
 __device__ __forceinline__ float filmic_curve(float x) {   // finalize.comp:21-31
@@ -97,13 +125,21 @@ __global__ __launch_bounds__(256) void k_finalize(const uint32_t* __restrict__ a
     out_bgra8[(size_t)(H - y - 1) * W + x] = out;                                                    // :60-62 (Y flip)
 }
 
-hipError_t launch_denoise(const void* lighting_in, const void* depth, const void* normal, int W, int H, int size, bool swapped,
-                          void* lighting_out, hipStream_t st) {
+hipError_t launch_denoise_prepare(const void* lighting, const void* depth, const void* normal, int W, int H, void* work,
+                                  hipStream_t st) {
+    const uint32_t n = (uint32_t)W * (uint32_t)H;
+    hipLaunchKernelGGL(k_denoise_prepare, dim3((n + 255u) / 256u), dim3(256), 0, st, (const ushort4*)lighting, (const uint16_t*)depth,
+                       (const uint8_t*)normal, n, (uint4*)work);
+    return hipGetLastError();
+}
+
+hipError_t launch_denoise(const void* work_in, int W, int H, int size, bool swapped, bool last, void* work_out, void* lighting,
+                          hipStream_t st) {
     dim3 grid((W + 63) / 64, (H + 3) / 4), block(256);
-    if (swapped) hipLaunchKernelGGL(k_denoise_pass<true>, grid, block, 0, st, (const ushort4*)lighting_in, (const uint16_t*)depth,
-                                    (const uint8_t*)normal, W, H, size, (ushort4*)lighting_out);
-    else hipLaunchKernelGGL(k_denoise_pass<false>, grid, block, 0, st, (const ushort4*)lighting_in, (const uint16_t*)depth,
-                            (const uint8_t*)normal, W, H, size, (ushort4*)lighting_out);
+#define RT_LAUNCH_DN(S, L) hipLaunchKernelGGL((k_denoise_pass<S, L>), grid, block, 0, st, (const uint4*)work_in, W, H, size, (uint4*)work_out, (ushort4*)lighting)
+    if (swapped) { if (last) RT_LAUNCH_DN(true, true); else RT_LAUNCH_DN(true, false); }
+    else { if (last) RT_LAUNCH_DN(false, true); else RT_LAUNCH_DN(false, false); }
+#undef RT_LAUNCH_DN
     return hipGetLastError();
 }
 
