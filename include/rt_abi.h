@@ -252,6 +252,14 @@ int rt_denoise(RtContext* ctx, int faithful);
  * -> RT_BUF_FINAL_BGRA8.  Whole-frame contexts only. Asynchronous. */
 int rt_finalize(RtContext* ctx);
 
+/* The same two passes on caller-owned row-major device planes of cfg.width x cfg.height pixels in the reference formats
+ * (e.g. the frame rt_untile_gbuffer assembled on rank 0 from the ranks' tiles): rt_denoise_planes filters `lighting_rgba16`
+ * in place, rt_finalize_planes writes `out_bgra8` (4 B/px, rows top-down).  Valid on any context, tile-split or not; the
+ * context supplies the stream, the blue-noise texture and the working memory.  Asynchronous. */
+int rt_denoise_planes(RtContext* ctx, void* lighting_rgba16, const void* depth_r16, const void* normal_r8, int faithful);
+int rt_finalize_planes(RtContext* ctx, const void* albedo_rgba8, const void* emission_rgba8, const void* fog_rgba8,
+                       const void* lighting_rgba16, const void* depth_r16, void* out_bgra8);
+
 int rt_get_counters(RtContext* ctx, RtCounters* out);
 int rt_reset_counters(RtContext* ctx);
 int rt_get_timing(RtContext* ctx, RtTiming* out);

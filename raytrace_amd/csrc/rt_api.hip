@@ -568,20 +568,17 @@ int rt_untile(RtContext* ctx, int id, const void* gathered_dev, int world, void*
     return RT_OK;
 }
 
-int rt_denoise(RtContext* ctx, int faithful) {
+int rt_denoise_planes(RtContext* ctx, void* lighting, const void* depth, const void* normal, int faithful) {
     if (!ctx) return RT_ERR_INVALID_ARG;
-    if (ctx->cfg.tile_world != 1) return fail(ctx, RT_ERR_UNIMPLEMENTED, "rt_denoise: whole-frame contexts only (gather the tiles first)");
-    if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_denoise: no frame drawn yet");
+    if (!lighting || !depth || !normal) return fail(ctx, RT_ERR_INVALID_ARG, "rt_denoise_planes: null plane");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int sizes[6] = {1, 2, 4, 8, 8, 16};                         // pipeline.rs:103
-    for (int i = 0; i < 2; i++)
-        if (!ctx->denoise_work[i]) { uint4* p = nullptr; RT_HIP(ctx, dev_alloc(ctx, &p, ctx->plane_pixels)); ctx->denoise_work[i] = p; }
     const int W = ctx->cfg.width, H = ctx->cfg.height;
-    void* lighting = ctx->planes[RT_BUF_LIGHTING_RGBA16];
+    for (int i = 0; i < 2; i++)
+        if (!ctx->denoise_work[i]) { uint4* p = nullptr; RT_HIP(ctx, dev_alloc(ctx, &p, (size_t)W * H)); ctx->denoise_work[i] = p; }
     {
         LaunchTimer t(ctx, 1);
-        RT_HIP(ctx, rtd::launch_denoise_prepare(lighting, ctx->planes[RT_BUF_DEPTH_R16UI], ctx->planes[RT_BUF_NORMAL_R8UI], W, H,
-                                                ctx->denoise_work[0], ctx->stream));
+        RT_HIP(ctx, rtd::launch_denoise_prepare(lighting, depth, normal, W, H, ctx->denoise_work[0], ctx->stream));
     }
     for (int pass = 0; pass < 6; pass++) {
         // pipeline.rs:104-108: the ping descriptor set on even dispatches, the pong set (normal/depth bindings swapped,
@@ -594,16 +591,31 @@ int rt_denoise(RtContext* ctx, int faithful) {
     return RT_OK;
 }
 
-int rt_finalize(RtContext* ctx) {
+int rt_finalize_planes(RtContext* ctx, const void* albedo, const void* emission, const void* fog, const void* lighting,
+                       const void* depth, void* out_bgra8) {
     if (!ctx) return RT_ERR_INVALID_ARG;
-    if (ctx->cfg.tile_world != 1) return fail(ctx, RT_ERR_UNIMPLEMENTED, "rt_finalize: whole-frame contexts only (gather the tiles first)");
-    if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_finalize: no frame drawn yet");
+    if (!albedo || !emission || !fog || !lighting || !depth || !out_bgra8) return fail(ctx, RT_ERR_INVALID_ARG, "rt_finalize_planes: null plane");
+    if (!ctx->has_noise) return fail(ctx, RT_ERR_NOT_READY, "rt_finalize_planes: noise must be uploaded first");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     LaunchTimer t(ctx, 1);
-    RT_HIP(ctx, rtd::launch_finalize(ctx->planes[RT_BUF_ALBEDO_RGBA8], ctx->planes[RT_BUF_EMISSION_RGBA8], ctx->planes[RT_BUF_FOG_RGBA8],
-                                     ctx->planes[RT_BUF_LIGHTING_RGBA16], ctx->planes[RT_BUF_DEPTH_R16UI], ctx->d_noise, ctx->cfg.width,
-                                     ctx->cfg.height, ctx->planes[RT_BUF_FINAL_BGRA8], ctx->stream));
+    RT_HIP(ctx, rtd::launch_finalize(albedo, emission, fog, lighting, depth, ctx->d_noise, ctx->cfg.width, ctx->cfg.height, out_bgra8,
+                                     ctx->stream));
     return RT_OK;
+}
+
+int rt_denoise(RtContext* ctx, int faithful) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->cfg.tile_world != 1) return fail(ctx, RT_ERR_UNIMPLEMENTED, "rt_denoise: whole-frame contexts only (gather the tiles, then rt_denoise_planes)");
+    if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_denoise: no frame drawn yet");
+    return rt_denoise_planes(ctx, ctx->planes[RT_BUF_LIGHTING_RGBA16], ctx->planes[RT_BUF_DEPTH_R16UI], ctx->planes[RT_BUF_NORMAL_R8UI], faithful);
+}
+
+int rt_finalize(RtContext* ctx) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->cfg.tile_world != 1) return fail(ctx, RT_ERR_UNIMPLEMENTED, "rt_finalize: whole-frame contexts only (gather the tiles, then rt_finalize_planes)");
+    if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_finalize: no frame drawn yet");
+    return rt_finalize_planes(ctx, ctx->planes[RT_BUF_ALBEDO_RGBA8], ctx->planes[RT_BUF_EMISSION_RGBA8], ctx->planes[RT_BUF_FOG_RGBA8],
+                              ctx->planes[RT_BUF_LIGHTING_RGBA16], ctx->planes[RT_BUF_DEPTH_R16UI], ctx->planes[RT_BUF_FINAL_BGRA8]);
 }
 
 void* rt_gbuffer_ptr(RtContext* ctx) { return ctx ? ctx->gbuffer : nullptr; }

@@ -168,6 +168,15 @@ class Context:
     def finalize(self):
         self._check(self._lib.rt_finalize(self._h))
 
+    def denoise_planes(self, lighting_ptr, depth_ptr, normal_ptr, faithful=True):
+        """The six denoise dispatches on caller-owned row-major device planes (e.g. the gathered frame on rank 0)."""
+        self._check(self._lib.rt_denoise_planes(self._h, C.c_void_p(lighting_ptr), C.c_void_p(depth_ptr), C.c_void_p(normal_ptr),
+                                                1 if faithful else 0))
+
+    def finalize_planes(self, albedo_ptr, emission_ptr, fog_ptr, lighting_ptr, depth_ptr, out_ptr):
+        self._check(self._lib.rt_finalize_planes(self._h, C.c_void_p(albedo_ptr), C.c_void_p(emission_ptr), C.c_void_p(fog_ptr),
+                                                 C.c_void_p(lighting_ptr), C.c_void_p(depth_ptr), C.c_void_p(out_ptr)))
+
     # -- instrumentation ---------------------------------------------------------------------------------
     def counters(self):
         cn = RtCounters()

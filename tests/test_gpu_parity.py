@@ -156,6 +156,7 @@ def test_tile_split_contexts_reassemble_to_the_full_frame(procedural_region, blu
     assert sum(c.tile_count() for c in ctxs) == ((W + 7) // 8) * ((H + 7) // 8)
     assert ctxs[0].tile_capacity() == ctxs[1].tile_capacity()
     dev = torch.device("cuda", 0)
+    frames = {}
     for b in range(abi.RT_BUF_FINAL_BGRA8):
         nbytes = ctxs[0].buffer_bytes(b)
         parts = [torch.from_numpy(c.readback(b).reshape(-1).view(np.uint8).copy()).to(dev) for c in ctxs]
@@ -170,6 +171,24 @@ def test_tile_split_contexts_reassemble_to_the_full_frame(procedural_region, blu
         torch.cuda.synchronize()
         got = frame.cpu().numpy().view(dt).reshape((H, W, ch) if ch > 1 else (H, W))
         assert np.array_equal(got, cpu[abi.BUFFER_NAMES[b]], equal_nan=True), abi.BUFFER_NAMES[b]
+        frames[b] = frame
+    # the post passes on the assembled frame (what rank 0 does after the gather): rt_denoise_planes / rt_finalize_planes
+    out = torch.zeros(W * H * 4, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    F = frames
+    ctxs[0].denoise_planes(F[abi.RT_BUF_LIGHTING_RGBA16].data_ptr(), F[abi.RT_BUF_DEPTH_R16UI].data_ptr(),
+                           F[abi.RT_BUF_NORMAL_R8UI].data_ptr(), faithful=True)
+    ctxs[0].finalize_planes(F[abi.RT_BUF_ALBEDO_RGBA8].data_ptr(), F[abi.RT_BUF_EMISSION_RGBA8].data_ptr(),
+                            F[abi.RT_BUF_FOG_RGBA8].data_ptr(), F[abi.RT_BUF_LIGHTING_RGBA16].data_ptr(),
+                            F[abi.RT_BUF_DEPTH_R16UI].data_ptr(), out.data_ptr())
+    ctxs[0].sync()
+    exp_den = po.denoise(cpu["lighting_rgba16"], cpu["depth_r16"], cpu["normal_r8"], faithful=True)
+    exp_fin = po.finalize(cpu["albedo_rgba8"], cpu["emission_rgba8"], cpu["fog_rgba8"], exp_den, cpu["depth_r16"], blue_noise)
+    den = F[abi.RT_BUF_LIGHTING_RGBA16].cpu().numpy().view(np.uint16).reshape(H, W, 4)
+    assert np.array_equal(den, exp_den)
+    assert np.array_equal(out.cpu().numpy().reshape(H, W, 4), exp_fin)
+    with pytest.raises(render.RtError):
+        ctxs[0].denoise()          # the context's own planes hold tiles, not a frame
     for c in ctxs:
         c.destroy()
 
