@@ -200,7 +200,8 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     // ---- path state ----
     uint32_t phase = PH_EMPTY;                // PH_EMPTY, PH_PRIMARY (F only, CACHE=false), PH_DIF (= a level: S and F)
     uint32_t item = 0, lp = 0, samp = 0, level = 0, sunbits = 0;
-    uint32_t dif_entry = 0;                   // diffuse-table entry of the level in flight (its slot 3 = sample_sky of that direction)
+    uint32_t dif_entry = 0xFFFFFFFFu;         // diffuse-table entry held by F's direction registers (its slot 3 = sample_sky of that direction)
+    uint32_t sun_entry = 0xFFFFFFFFu;         // shadow-table entry held by S's direction registers
     uint32_t nvtex = 0;                       // noise_value texel of the path (raytrace.comp:324,336)
     bool exhausted = false;
     constexpr uint32_t kChunk = 512;
@@ -303,8 +304,10 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 // fetches of both slots first (:106 for a fresh ray, :137 otherwise), so their latencies overlap
                 // nibble-map entry: at R = 256 a coarse cube IS the 4^3 brick, so the entry index is vox >> 6
                 const uint32_t bS = LOGR == 8 ? S.vox >> 6 : S.cidx, bF = LOGR == 8 ? F.vox >> 6 : F.cidx;
-                const uint32_t wS = s_coarse[bS >> 3], wF = s_coarse[bF >> 3];
-                uint32_t stS = (wS >> ((bS & 7u) << 2)) & 15u, stF = (wF >> ((bF & 7u) << 2)) & 15u;
+                // byte reads: entry b is nibble (b & 1) of byte b >> 1 (little-endian words, k_build_coarse)
+                const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
+                const uint32_t wS = s_nib[bS >> 1], wF = s_nib[bF >> 1];
+                uint32_t stS = (wS >> ((bS & 1u) << 2)) & 15u, stF = (wF >> ((bF & 1u) << 2)) & 15u;
                 const bool gS = S.tracing && stS == kNibMixed, gF = F.tracing && stF == kNibMixed;
                 uint8_t byS = 0, byF = 0;
                 if (gS) byS = sc.mine[S.vox];
@@ -456,13 +459,22 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             int ix, iy, iz;
             const bool ok = wrap_texel(ro, (float)R, &ix, &iy, &iz);
             const uint32_t vox0 = swizzled_index(ix, iy, iz, LB), cidx0 = coarse_index(ix, iy, iz, LOGR);
-            const float4 sd = a.sun_lut[2u * (nvtex & 0xFFFFu)], sl = a.sun_lut[2u * (nvtex & 0xFFFFu) + 1u];
-            S.dx = sd.x; S.dy = sd.y; S.dz = sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
+            // Stepping never touches a slot's direction registers, so they still hold the table entry of the previous
+            // level: the shadow entry depends on the path's noise texel only (same for all its levels, Q5) and the
+            // diffuse entry repeats whenever the next surface has the same face — skip those table reads.
+            const uint32_t se = nvtex & 0xFFFFu;
+            if (se != sun_entry) {
+                const float4 sd = a.sun_lut[2u * se], sl = a.sun_lut[2u * se + 1u];
+                S.dx = sd.x; S.dy = sd.y; S.dz = sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
+                sun_entry = se;
+            }
             arm(S, ro, ok, vox0, cidx0);
-            const uint32_t di = 4u * ((snormal << 16) | (nvtex & 0xFFFFu));
-            const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
-            dif_entry = di;
-            F.dx = d2.x; F.dy = d2.y; F.dz = d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
+            const uint32_t di = 4u * ((snormal << 16) | se);
+            if (di != dif_entry) {
+                const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
+                F.dx = d2.x; F.dy = d2.y; F.dz = d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
+                dif_entry = di;
+            }
             arm(F, ro, ok, vox0, cidx0);
             phase = PH_DIF;
         }
@@ -474,6 +486,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             int ix, iy, iz;
             const bool ok = wrap_texel(ro, (float)R, &ix, &iy, &iz);
             set_dir(F, rd);
+            dif_entry = 0xFFFFFFFFu;   // F's direction registers no longer hold a table entry
             arm(F, ro, ok, swizzled_index(ix, iy, iz, LB), coarse_index(ix, iy, iz, LOGR));
             phase = PH_PRIMARY;
             if (COUNT) c_prim++;
