@@ -87,8 +87,6 @@ def main():
     import torch.distributed as dist
     from raytrace_amd import abi, build, render, world as rt_world
 
-    if rank == 0:
-        build.build()
     # RT_BENCH_BACKEND=gloo + RT_BENCH_SINGLE_DEVICE=1 rehearse the N>1 path on a one-GPU box (every rank on GPU 0, planes
     # staged through host memory for the gather); the real run uses RCCL ("nccl") with one GPU per rank.
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
@@ -106,6 +104,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        dist.barrier()
+    # the native libraries travel prebuilt; if they are stale rank 0 rebuilds them before any rank loads them
+    if rank == 0:
+        build.build()
+    if dist_on:
         dist.barrier()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -47,7 +47,7 @@ def _stale(target, deps):
 
 
 def _run(cmd):
-    print("+", " ".join(cmd), flush=True)
+    print("+", " ".join(cmd), file=sys.stderr, flush=True)   # stderr: bench.py's stdout carries one JSON line only
     subprocess.check_call(cmd)
 
 
