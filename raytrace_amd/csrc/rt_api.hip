@@ -77,7 +77,7 @@ struct RtContext {
     float4* pacc = nullptr;
     float4* ppl = nullptr;
     uint32_t persist_batch = 1;
-    uint32_t persist_threshold = 32, persist_threshold_sun = 16;
+    uint32_t persist_threshold = 32;
     rtd::DevCounters* d_counters = nullptr;
     uint64_t host_noise_base = 0, host_frames = 0;
 
@@ -337,7 +337,6 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
 
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
-    if (const char* s = getenv("RT_PERSIST_THRESHOLD_SUN")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold_sun = (uint32_t)v; }
     if (c->kernel == RT_KERNEL_PERSISTENT) {
         RT_HIP_CREATE(dev_alloc(c, &c->pcursor, 2));
         RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));

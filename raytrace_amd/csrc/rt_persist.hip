@@ -9,9 +9,10 @@
 //               which it walks together.  All lanes run the same DDA step loop.  A lane whose rays have ended parks;
 //               when `threshold` lanes of the wave are parked (__ballot) the wave runs ONE transition pass for all of
 //               them — consume the results, shade, start the next level (directions come from tables), or finish
-//               the path and pull the next one from the global cursor (one atomicAdd per wave, ballot-ranked) — so
-//               shading runs on a well-filled wave and the step loop on compacted work.  Per path only 12 bytes of
-//               light go to HBM (SoA, coalesced); k_accumulate_paths adds a pixel's samples in order.
+//               the path and pull the next one from the wave's 512-path chunk of the global cursor (one atomicAdd per
+//               chunk, paths dealt out ballot-ranked) — so shading runs on a well-filled wave and the step loop on
+//               compacted work.  Per path one 16-byte light record goes to HBM; k_accumulate_paths adds a pixel's
+//               samples in order.
 //
 // The primary ray does not depend on the seed (raytrace.comp:306-320 reads no noise), so with RT_FLAG_CACHE_PRIMARY
 // it is traced once per pixel (k_primary) and every sample starts at its first shadow ray.  Without the flag
