@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4)
-    ap.add_argument("--kernel", choices=["persistent", "wavefront", "mega"], default="persistent")
+    ap.add_argument("--kernel", choices=["persistent", "persistent2", "wavefront", "mega"], default="persistent")
     ap.add_argument("--no-cache-primary", dest="cache_primary", action="store_false",
                     help="re-trace the (seed-independent) primary ray for every sample, like spp reference frames would")
     ap.set_defaults(cache_primary=True)
@@ -114,7 +114,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     W, H, SPP, D = args.width, args.height, args.spp, args.depth
-    kernel = {"persistent": abi.RT_KERNEL_PERSISTENT, "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
+    kernel = {"persistent": abi.RT_KERNEL_PERSISTENT, "persistent2": abi.RT_KERNEL_PERSISTENT2, "wavefront": abi.RT_KERNEL_WAVEFRONT,
+              "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
     noise = np.fromfile(os.path.join(ROOT, "tests", "golden", "blue_noise_512.rgba"), dtype=np.uint8)
     REGION = args.region
@@ -143,7 +144,7 @@ def main():
     trace_bytes_local = cn.minefield_fetches + 4 * cn.material_fetches
     balg_local = cn.algorithmic_bytes()
     ref_equiv_rays_local = cn.rays + (SPP - 1) * cn.pixels if args.cache_primary else cn.rays
-    if args.kernel == "persistent" and args.cache_primary and D >= 1:
+    if args.kernel in ("persistent", "persistent2") and args.cache_primary and D >= 1:
         # the dominant kernel (k_persist) walks only shadow/diffuse rays; the primary prepass (k_primary) is a separate,
         # untimed-for-roofline launch: subtract its share, measured with a depth-0 counting frame
         cfg0 = render.make_config(W, H, spp=SPP, depth=0, device=local_rank, tile_rank=rank, tile_world=world,
@@ -246,7 +247,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_r1.json")
         if os.path.exists(tpath) and (W, H, SPP, D, REGION) == (1920, 1080, 64, 4, 256) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get("k_%s_hbm_bytes_per_launch" % {"persistent": "persist", "wavefront": "trace", "mega": "mega"}[args.kernel])
+                traffic = json.load(open(tpath)).get("k_%s_hbm_bytes_per_launch" % {"persistent": "persist", "persistent2": "persist2", "wavefront": "trace", "mega": "mega"}[args.kernel])
             except Exception:
                 traffic = None
         out = {
@@ -258,7 +259,7 @@ def main():
                                    % ((W, H, SPP, D, REGION) + tuple(pose["origin"])), "kernel": args.kernel, "rays_per_frame": int(rays_total), "reference_equivalent_rays_per_frame": int(ref_rays_total),
                        "algorithmic_bytes_per_frame": int(balg_total), "parallelism": "tiles%d" % world,
                        "primary_cache": bool(args.cache_primary), "frame_sha256_16": frame_sha},
-            "roofline": {"bound": "hbm", "kernel": {"persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}[args.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": {"persistent": "k_persist", "persistent2": "k_persist2", "wavefront": "k_trace", "mega": "k_mega"}[args.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launches_per_frame": trace_launches // max(args.steps, 1),
                          "avg_launch_ms": round(trace_ms / max(trace_launches, 1), 4),

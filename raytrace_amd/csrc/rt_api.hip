@@ -77,7 +77,8 @@ struct RtContext {
     float4* pacc = nullptr;
     float4* ppl = nullptr;
     uint32_t persist_batch = 1;
-    uint32_t persist_threshold = 32;
+    uint32_t persist_threshold = 0, persist_rmin = 16;   // threshold 0 = the kernel version's default
+    int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2)
     rtd::DevCounters* d_counters = nullptr;
     uint64_t host_noise_base = 0, host_frames = 0;
 
@@ -265,7 +266,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (cfg->depth < 0 || cfg->depth > RT_MAX_DEPTH) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: depth out of range");
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: bad tile_rank/tile_world");
-    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_PERSISTENT)
+    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_PERSISTENT2)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown kernel");
 
     int ndev = 0;
@@ -287,6 +288,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     c->logr = cfg->region == 256 ? 8 : (cfg->region == 512 ? 9 : 10);
     c->vox = (size_t)cfg->region * cfg->region * cfg->region;
     c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PERSISTENT : cfg->kernel;
+    if (c->kernel == RT_KERNEL_PERSISTENT2) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 2; }   // same pipeline, other path kernel
     RT_HIP_CREATE(hipSetDevice(c->device));
     hipDeviceProp_t prop;
     RT_HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
@@ -337,9 +339,11 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
 
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
+    if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
+    if (c->persist_threshold == 0) c->persist_threshold = c->persist_version == 2 ? 48u : 32u;   // measured optima
     if (c->kernel == RT_KERNEL_PERSISTENT) {
         RT_HIP_CREATE(dev_alloc(c, &c->pcursor, 2));
-        RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));
+        RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)2 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));
         RT_HIP_CREATE(dev_alloc(c, &c->worklist, (size_t)c->npix_pad));
         RT_HIP_CREATE(dev_alloc(c, &c->phx, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->phy, (size_t)c->npix_pad));
         RT_HIP_CREATE(dev_alloc(c, &c->phz, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->pinfo, (size_t)c->npix_pad));
@@ -496,14 +500,14 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 if (s0 != 0) e = hipMemsetAsync(ctx->pcursor, 0, sizeof(uint32_t), ctx->stream);
                 rtd::PersistArgs pa{};
                 pa.cursor = ctx->pcursor; pa.worklist = ctx->worklist; pa.wl_count = ctx->pcursor + 1;
-                pa.npix_pad = ctx->npix_pad; pa.sample0 = s0; pa.nsamples = ns; pa.threshold = ctx->persist_threshold;
+                pa.npix_pad = ctx->npix_pad; pa.sample0 = s0; pa.nsamples = ns; pa.threshold = ctx->persist_threshold; pa.rmin = ctx->persist_rmin;
                 pa.nthreads = (uint32_t)ctx->num_cus * 1024u; pa.stack = ctx->pstack;
                 pa.phx = ctx->phx; pa.phy = ctx->phy; pa.phz = ctx->phz; pa.pinfo = ctx->pinfo;
                 pa.sun_lut = ctx->sun_lut; pa.dif_lut = ctx->dif_lut;
                 pa.pl = ctx->ppl; pa.counters = ctx->d_counters;
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 0);
-                    e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->num_cus, ctx->stream);
+                    e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->persist_version, ctx->num_cus, ctx->stream);
                 }
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 1);

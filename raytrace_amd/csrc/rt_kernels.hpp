@@ -63,8 +63,9 @@ struct PersistArgs {
     uint32_t npix_pad;          // CACHE=false: nwork = all local pixels (padded to whole 8x8 tiles)
     uint32_t sample0, nsamples; // samples of this batch: sample0 .. sample0+nsamples-1
     uint32_t threshold;         // parked lanes per wave that trigger a transition pass (1..64)
+    uint32_t rmin;              // k_persist2: contexts waiting for their diffuse ray that trigger the in-loop re-arm block
     uint32_t nthreads;          // grid size in threads (stride of the albedo stack)
-    uint32_t* stack;            // [(depth-1)][nthreads] packed material of surface j+1 (only touched when depth >= 2)
+    uint32_t* stack;            // [2][(depth-1)][nthreads] packed material of surface j+1 (only touched when depth >= 2; k_persist uses half)
     const float *phx, *phy, *phz;   // CACHE: primary hit per local pixel
     const uint32_t* pinfo;
     const float4* sun_lut;      // [2*65536] per-frame shadow-ray table: direction, 1/|direction|
@@ -81,7 +82,7 @@ hipError_t launch_sun_lut(const Frame& f, float4* lut, hipStream_t st);
 hipError_t launch_sky_lut(const Frame& f, float4* dif_lut, hipStream_t st);
 hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count, hipStream_t st);
 hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
-                          int nworkgroups, hipStream_t st);
+                          int version /* 1 = k_persist, 2 = k_persist2 */, int nworkgroups, hipStream_t st);
 
 hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
                           uint32_t* coarse, uint32_t* bad_flag, int logr, hipStream_t st);

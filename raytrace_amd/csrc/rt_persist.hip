@@ -22,6 +22,8 @@
 // Values are those of raytrace.comp; only the grouping of the work differs (see the loop note in rt_kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
 
@@ -509,6 +511,447 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     }
 }
 
+// =====================================================================================================
+// k_persist2 — two paths per lane, one ray slot each
+// =====================================================================================================
+// Same work, same values as k_persist; the grouping differs.  A lane carries TWO paths (contexts A and B).  A context
+// walks the two rays of its level one after the other in its single ray slot — the shadow ray first, then the diffuse
+// ray from the same surface point (its table entry waits in registers) — so a slot is busy for the whole level instead
+// of the shorter ray's slot idling, and the two contexts give the lane the two independent fetch chains k_persist got
+// from its two slots.  A context whose shadow ray ended is re-armed with the diffuse ray by a short block inside the
+// step loop (run when `rmin` contexts wait); a context whose diffuse ray ended parks, and because the lane's other
+// context keeps stepping, the transition pass can wait for a well-filled wave (`threshold` lanes with a parked context)
+// without idling the step loop.  The pass serves one context per lane: lanes whose parked context is B swap A and B
+// first (v_swap_b32), so there is one copy of the pass code.
+enum : uint32_t { P2_EMPTY = 0, P2_PRIMARY = 1, P2_SHADOW = 2, P2_DIF = 3 };
+
+// Ray slot of k_persist2.  Register diet (two contexts must fit 128 VGPRs without spilling):
+// * it keeps the NEGATED direction: with lr = 0, q = (d > 0 ? -u : u) (raytrace.comp:94-98,119) is then one v_bfi of u
+//   with the sign of nd (u > 0 inside the region), the position update fma(d, t, p) is fma(-nd, t, p) with a free source
+//   modifier, and RaySlot's three sign words are not needed.  (For d = +0 the sign of q differs from RaySlot's; that axis
+//   has 1/|d| = inf, so its boundary distance is inf either way and is never the minimum.)
+// * nk = iteration count | kind << 16 (kind is written when the ray ends); "fresh" is nk == 0.
+struct RaySlot2 {
+    float px, py, pz, ndx, ndy, ndz, lx, ly, lz, ux, uy, uz;
+    uint32_t vox, cidx, nk, axis;
+    bool tracing, valid, fresh_invalid;   // valid: only the lr != 0 build steps with it; fresh_invalid: counting build only
+};
+struct Ctx2 {
+    RaySlot2 r;
+    // the level's diffuse ray, waiting for the shadow ray to end: table entry (direction, 1/|direction|) in registers, the
+    // first texel (ovox, bit 31 = inside the texture) in a register, the origin in LDS (s_org)
+    float qdx, qdy, qdz, qlx, qly, qlz;
+    uint32_t ovox, ocidx;
+    // path state: st = phase | level << 2 | id << 7 | face id of the level's surface << 8 (id: which of the lane's two
+    // stack / origin areas the path uses — it travels with the path when the contexts swap);
+    // sn = noise_value texel bytes (r, g) of the path | shadow bits << 16 (bit j-1: shadow ray of level j reached the sky)
+    uint32_t st, item, sn, lp, samp;
+};
+__device__ __forceinline__ uint32_t c2_phase(const Ctx2& c) { return c.st & 3u; }
+__device__ __forceinline__ uint32_t c2_level(const Ctx2& c) { return c.st >> 2 & 31u; }
+__device__ __forceinline__ uint32_t c2_id(const Ctx2& c) { return c.st >> 7 & 1u; }
+__device__ __forceinline__ uint32_t c2_face(const Ctx2& c) { return c.st >> 8 & 7u; }
+__device__ __forceinline__ void c2_set_phase(Ctx2& c, uint32_t ph) { c.st = (c.st & ~3u) | ph; }
+__device__ __forceinline__ bool c2_parks(const Ctx2& c, bool exhausted) {   // parks when its ray has ended
+    const uint32_t ph = c.st & 3u;
+    return ph == P2_DIF || ph == P2_PRIMARY || (ph == P2_EMPTY && !exhausted);
+}
+__device__ __forceinline__ uint32_t r2_kind(const RaySlot2& r) { return r.nk >> 16; }
+
+__device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swapb(bool& a, bool& b) { const bool t = a; a = b; b = t; }
+
+template <int LOGR, bool LRZ, bool COUNT, bool CACHE>
+__global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes pl, PersistArgs a) {
+    __shared__ uint32_t s_coarse[kCoarseWords];
+    __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
+    __shared__ float s_org[2][3][1024];        // origin of the waiting diffuse ray: [path id][component][thread]
+    const uint32_t nwork = CACHE ? *a.wl_count : a.npix_pad;
+    const uint32_t nitems = nwork * a.nsamples;
+    if (nitems == 0u) return;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.coarse);
+        uint4* dst = reinterpret_cast<uint4*>(s_coarse);
+        for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
+        if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t threshold = a.threshold, rmin = a.rmin;
+    constexpr int R = 1 << LOGR, LB = LOGR - 2;
+    const float half = (float)R / 2;
+    const uint32_t D = (uint32_t)f.depth;
+    const uint32_t stack_levels = D > 1u ? D - 1u : 1u;
+
+    Ctx2 A, B;
+    {
+        RaySlot2& S = A.r;
+        S.px = S.py = S.pz = S.ndx = S.ndy = S.lx = S.ly = S.lz = S.ux = S.uy = S.uz = 0.0f; S.ndz = -1.0f;
+        S.vox = S.cidx = 0u; S.nk = PX_HIT << 16; S.axis = 2u;
+        S.tracing = false; S.valid = true; S.fresh_invalid = false;
+        A.qdx = A.qdy = A.qlx = A.qly = A.qlz = 0.0f; A.qdz = 1.0f;
+        A.ovox = A.ocidx = 0u;
+        A.st = P2_EMPTY | 7u << 8;   // face id 7: q* hold no table entry yet
+        A.item = A.sn = A.lp = A.samp = 0u;
+        B = A; B.st |= 1u << 7;
+    }
+    bool exhausted = false;
+    constexpr uint32_t kChunk = 512;
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of the path range
+    uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot) of path chunk_next
+
+    unsigned long long c_prim = 0, c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0,
+                       c_noise = 0, c_pix = 0;
+    unsigned long long d_iters = 0, d_sx = 0, d_fx = 0, d_sl = 0, d_fl = 0, d_pass = 0, d_pl = 0, d_sky = 0;   // wave-uniform
+
+    // ---- one DDA step: fetch value `step` already looked up (the arithmetic of k_persist's advance) -----------------
+    auto advance_t = [&](RaySlot2& r, uint32_t step, auto generic_q) {
+        if (!LRZ && !r.valid) step = 0u;
+        if (step == 0u) {
+            // a fresh ray on a 0 has step_size 0 => mod(x,0) = NaN (defined outcome), otherwise a hit
+            r.nk = r.nk == 0u ? (1u | PX_SPECIAL << 16) : (r.nk | PX_HIT << 16);
+            r.tracing = false;
+        } else if (r.nk == (uint32_t)RT_TRACE_LIMIT) {
+            r.nk |= PX_LIMIT << 16; r.tracing = false;                                              // :109 (Q8)
+        } else {
+            const uint32_t sb = (step << 23) + (126u << 23);          // float((1 << step) / 2)
+            const float sz = __builtin_bit_cast(float, sb);
+            const float is = __builtin_bit_cast(float, 0x7F000000u - sb);   // exactly 1/sz
+            // q = (d > 0 ? -u : u) (:94-98,119).  With lr = 0, in the step loop u > 0 (u = p + half, |p| < half after a
+            // step), so q is u with the sign of nd: one v_bfi.  Only a ray's FIRST step can see u < 0 (origin outside the
+            // region, or the 0.001 face offset across its edge); arm() takes that step itself with the general form.
+            float qx, qy, qz;
+            if (decltype(generic_q)::value || !LRZ) {   // a scrolled region (lr != 0) has u = p + half of either sign
+                qx = r.ndx < 0.0f ? -r.ux : r.ux; qy = r.ndy < 0.0f ? -r.uy : r.uy; qz = r.ndz < 0.0f ? -r.uz : r.uz;
+            } else {
+                qx = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, r.ux) & 0x7FFFFFFFu) | (__builtin_bit_cast(uint32_t, r.ndx) & 0x80000000u));
+                qy = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, r.uy) & 0x7FFFFFFFu) | (__builtin_bit_cast(uint32_t, r.ndy) & 0x80000000u));
+                qz = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, r.uz) & 0x7FFFFFFFu) | (__builtin_bit_cast(uint32_t, r.ndz) & 0x80000000u));
+            }
+            const float mx = __builtin_fmaf(-sz, rtm_floor(qx * is), qx);   // == q - sz*floor(q/sz): both products exact
+            const float my = __builtin_fmaf(-sz, rtm_floor(qy * is), qy);
+            const float mz = __builtin_fmaf(-sz, rtm_floor(qz * is), qz);
+            const float tx = (0.0001f + mx) * r.lx, ty = (0.0001f + my) * r.ly, tz = (0.0001f + mz) * r.lz;
+            const bool xy = tx < ty;
+            const float m1 = xy ? tx : ty;
+            const bool useZ = !(m1 < tz);
+            const float t = useZ ? tz : m1;
+            r.axis = useZ ? 2u : (xy ? 0u : 1u);
+            r.px = __builtin_fmaf(-r.ndx, t, r.px); r.py = __builtin_fmaf(-r.ndy, t, r.py); r.pz = __builtin_fmaf(-r.ndz, t, r.pz);   // fused (rt_math.h contract)
+            r.nk++;
+            r.ux = r.px + half; r.uy = r.py + half; r.uz = r.pz + half;
+            const bool sky = LRZ ? (rtm_abs(r.px) >= half || rtm_abs(r.py) >= half || rtm_abs(r.pz) >= half)
+                                 : (rtm_abs(r.px - f.lr[0]) >= half || rtm_abs(r.py - f.lr[1]) >= half || rtm_abs(r.pz - f.lr[2]) >= half);
+            if (sky) {
+                r.nk |= PX_AIR << 16; r.tracing = false;
+            } else if (LRZ) {
+                const int ix = (int)r.ux & (R - 1), iy = (int)r.uy & (R - 1), iz = (int)r.uz & (R - 1);
+                r.vox = swizzled_index(ix, iy, iz, LB);
+                if (LOGR != 8) r.cidx = coarse_index(ix, iy, iz, LOGR);
+            } else {
+                int ix, iy, iz;
+                r.valid = wrap_texel(v3(r.px, r.py, r.pz), (float)R, &ix, &iy, &iz);
+                if (COUNT && !r.valid) c_border++;
+                r.vox = swizzled_index(ix, iy, iz, LB);
+                if (LOGR != 8) r.cidx = coarse_index(ix, iy, iz, LOGR);
+            }
+        }
+    };
+    auto advance = [&](RaySlot2& r, uint32_t step) { advance_t(r, step, std::false_type{}); };
+    // ---- head of trace_ray (:83-107); needs r.l* set ------------------------------------------------------------------
+    auto arm = [&](RaySlot2& r, float dx, float dy, float dz, float rox, float roy, float roz, bool ok, uint32_t vox0,
+                   uint32_t cidx0) {
+        r.px = rox; r.py = roy; r.pz = roz;
+        r.ndx = -dx; r.ndy = -dy; r.ndz = -dz;
+        r.ux = rox + half; r.uy = roy + half; r.uz = roz + half;
+        r.valid = true; r.fresh_invalid = !ok; r.vox = vox0; r.cidx = cidx0;
+        r.nk = 0; r.axis = 2; r.tracing = true;
+        // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
+        if (dx != dx || dy != dy || dz != dz || !ok) { r.nk = 1u | PX_SPECIAL << 16; r.tracing = false; }
+        if (LRZ && r.tracing && (r.ux < 0.0f || r.uy < 0.0f || r.uz < 0.0f)) {   // rare: see advance_t
+            const uint32_t b = LOGR == 8 ? r.vox >> 6 : r.cidx;
+            uint32_t st = (reinterpret_cast<const uint8_t*>(s_coarse)[b >> 1] >> ((b & 1u) << 2)) & 15u;
+            if (st == kNibMixed) st = sc.mine[r.vox];
+            advance_t(r, st, std::true_type{});
+        }
+    };
+    auto tally = [&](const RaySlot2& r) {   // exact counters of one finished ray
+        const uint32_t kind = r2_kind(r);
+        c_iter += r.nk & 0xFFFFu;
+        if (kind == PX_AIR) {
+            c_sky++;
+            int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
+            if (!wrap_texel(v3(r.px, r.py, r.pz), (float)R, &tx, &ty, &tz)) c_border++;
+        } else if (kind == PX_LIMIT) c_limit++;
+        else c_hits++;
+        if (kind == PX_SPECIAL) c_border += 1u + (r.fresh_invalid ? 1u : 0u);
+        else if (r.fresh_invalid) c_border++;
+    };
+    // the shadow ray of a context ended: note its result (:326-328 / :338-340) and start the level's diffuse ray (:330 / :342)
+    auto rearm = [&](Ctx2& c) {
+        if (c2_phase(c) == P2_SHADOW && !c.r.tracing) {
+            if (COUNT) tally(c.r);
+            if (r2_kind(c.r) == PX_AIR) c.sn |= 0x8000u << c2_level(c);   // bit 16 + level - 1
+            c.r.lx = c.qlx; c.r.ly = c.qly; c.r.lz = c.qlz;
+            const uint32_t id = c2_id(c);
+            arm(c.r, c.qdx, c.qdy, c.qdz, s_org[id][0][threadIdx.x], s_org[id][1][threadIdx.x], s_org[id][2][threadIdx.x],
+                (c.ovox >> 31) != 0u, c.ovox & 0x7FFFFFFFu, c.ocidx);
+            c2_set_phase(c, P2_DIF);
+        }
+    };
+
+    // wave-uniform lane masks.  sh* = context is on its shadow ray; pk* = a context that parks when its ray ends (diffuse or
+    // primary ray in flight, or no path while paths are left)
+    uint64_t mA = 0, mB = 0, shA = 0, shB = 0, pkA = ~0ull, pkB = ~0ull;
+    for (;;) {
+        uint64_t need = (~mA & pkA) | (~mB & pkB);
+        if ((uint32_t)__popcll(need) < threshold && (mA | mB) != 0ull) {
+            // ---- step loop ----------------------------------------------------------------------------------------
+            do {
+                // fetches of both contexts first (:106 for a fresh ray, :137 otherwise), so their latencies overlap
+                const uint32_t bA = LOGR == 8 ? A.r.vox >> 6 : A.r.cidx, bB = LOGR == 8 ? B.r.vox >> 6 : B.r.cidx;
+                const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
+                const uint32_t wA = s_nib[bA >> 1], wB = s_nib[bB >> 1];
+                uint32_t stA = (wA >> ((bA & 1u) << 2)) & 15u, stB = (wB >> ((bB & 1u) << 2)) & 15u;
+                const bool gA = A.r.tracing && stA == kNibMixed, gB = B.r.tracing && stB == kNibMixed;
+                uint8_t byA = 0, byB = 0;
+                if (gA) byA = sc.mine[A.r.vox];
+                if (gB) byB = sc.mine[B.r.vox];
+                if (gA) stA = byA;
+                if (gB) stB = byB;
+                if (COUNT) {
+                    const uint32_t nA = (uint32_t)__popcll(mA), nB = (uint32_t)__popcll(mB);
+                    d_iters++; if (nA) { d_sx++; d_sl += nA; } if (nB) { d_fx++; d_fl += nB; }
+                }
+                if (A.r.tracing) advance(A.r, stA);
+                if (B.r.tracing) advance(B.r, stB);
+                mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
+                const uint64_t rA = shA & ~mA, rB = shB & ~mB;
+                const uint32_t nre = (uint32_t)__popcll(rA) + (uint32_t)__popcll(rB);
+                if (nre >= rmin || ((mA | mB) == 0ull && nre != 0u)) {
+                    rearm(A); rearm(B);
+                    mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
+                    shA &= ~rA; shB &= ~rB; pkA |= rA; pkB |= rB;
+                }
+                need = (~mA & pkA) | (~mB & pkB);
+            } while ((uint32_t)__popcll(need) < threshold && (mA | mB) != 0ull);
+            continue;
+        }
+        if (need == 0ull) {
+            // no ray in flight and no context parked: only finished shadow rays can be left
+            const uint64_t rA = shA & ~mA, rB = shB & ~mB;
+            if ((rA | rB) == 0ull) break;             // ... or nothing at all: the wave is done
+            rearm(A); rearm(B);
+            mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
+            shA &= ~rA; shB &= ~rB; pkA |= rA; pkB |= rB;
+            continue;
+        }
+
+        // =========================== transition pass ===========================================================
+        // The pass serves context A.  Lanes whose parked context is B (and whose A is not parked) swap the two.
+        {
+            const bool parkA = !A.r.tracing && c2_parks(A, exhausted);
+            const bool parkB = !B.r.tracing && c2_parks(B, exhausted);
+            if (parkB && !parkA) {
+                swap32(A.r.px, B.r.px); swap32(A.r.py, B.r.py); swap32(A.r.pz, B.r.pz);
+                swap32(A.r.ndx, B.r.ndx); swap32(A.r.ndy, B.r.ndy); swap32(A.r.ndz, B.r.ndz);
+                swap32(A.r.lx, B.r.lx); swap32(A.r.ly, B.r.ly); swap32(A.r.lz, B.r.lz);
+                swap32(A.r.ux, B.r.ux); swap32(A.r.uy, B.r.uy); swap32(A.r.uz, B.r.uz);
+                swap32(A.r.vox, B.r.vox); if (LOGR != 8) swap32(A.r.cidx, B.r.cidx);
+                swap32(A.r.nk, B.r.nk); swap32(A.r.axis, B.r.axis);
+                swapb(A.r.tracing, B.r.tracing);
+                if (!LRZ) swapb(A.r.valid, B.r.valid);
+                if (COUNT) swapb(A.r.fresh_invalid, B.r.fresh_invalid);
+                swap32(A.qdx, B.qdx); swap32(A.qdy, B.qdy); swap32(A.qdz, B.qdz);
+                swap32(A.qlx, B.qlx); swap32(A.qly, B.qly); swap32(A.qlz, B.qlz);
+                swap32(A.ovox, B.ovox); if (LOGR != 8) swap32(A.ocidx, B.ocidx);
+                swap32(A.st, B.st); swap32(A.item, B.item); swap32(A.sn, B.sn);
+                if (!CACHE) { swap32(A.lp, B.lp); swap32(A.samp, B.samp); }
+            }
+        }
+        RaySlot2& F = A.r;
+        const uint32_t phaseA = c2_phase(A);
+        const bool mine = !F.tracing && (phaseA == P2_DIF || phaseA == P2_PRIMARY);
+        if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); }
+        bool begin_level = false, need_primary = false;
+        uint32_t new_level = 0;
+        float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
+        uint32_t snormal = 0;
+        if (mine) {
+            // Diffuse / primary result (see k_persist)
+            const uint32_t kind = r2_kind(F);
+            const bool air = kind == PX_AIR;
+            const uint32_t nrm = F.axis == 0 ? (F.ndx < 0.0f ? 1u : 0u) : (F.axis == 1 ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
+            uint32_t material = 0;
+            if (kind == PX_HIT && (LRZ || F.valid)) material = sc.mat[F.vox];
+            float hx = F.px, hy = F.py, hz = F.pz;
+            if (kind == PX_SPECIAL) { hx = hy = hz = __builtin_nanf(""); }
+            const float off = 0.001f;
+            if (nrm == 0) hx += off; else if (nrm == 1) hx -= off;
+            else if (nrm == 2) hy += off; else if (nrm == 3) hy -= off;
+            else if (nrm == 4) hz += off; else hz -= off;
+            if (COUNT) tally(F);
+            bool path_done = false;
+            vec3 light = v3(0, 0, 0);
+            if (!CACHE && phaseA == P2_PRIMARY) {
+                PixelId pix = pixel_of_local(f, A.lp);
+                vec3 pstart, pdir;
+                primary_ray(f, pix.px, pix.py, &pstart, &pdir);
+                if (A.samp == 0u) {
+                    store_primary_planes(pl, pix.out_index, f, pdir, air, nrm, material, v3(hx, hy, hz));
+                    if (COUNT) c_pix++;
+                }
+                if (air) {
+                    light = sample_sky(pdir, ld3(f.sunangle), ld3(f.sunlight), true);               // :321-322
+                    path_done = true;
+                } else if (D < 1u) {
+                    path_done = true;
+                } else {
+                    sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
+                    new_level = 1; A.sn &= 0xFFFFu; begin_level = true;
+                }
+            } else {
+                // a level ended: its shadow result is already in the shadow bits (rearm); now the diffuse result
+                const uint32_t level = c2_level(A), sunbits = A.sn >> 16;
+                if (air || level == D) {
+                    const vec3 sunlight = ld3(f.sunlight);
+                    vec3 sky = v3(0, 0, 0);
+                    if (air) { const float4 t = a.dif_lut[4u * ((c2_face(A) << 16) | (A.sn & 0xFFFFu)) + 3u]; sky = v3(t.x, t.y, t.z); }   // :331-332 / :343-345, tabulated
+                    // L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
+                    vec3 L = v3(0.0f, 0.0f, 0.0f);
+                    if (sunbits >> (level - 1) & 1u) L = vadd(L, sunlight);
+                    if (air) L = vadd(L, sky);
+                    for (uint32_t j = level - 1; j >= 1u; j--) {
+                        const uint32_t pm = a.stack[((size_t)c2_id(A) * stack_levels + (j - 1)) * a.nthreads + gtid];
+                        vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
+                        light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
+                        vec3 acc = v3(0.0f, 0.0f, 0.0f);
+                        if (sunbits >> (j - 1) & 1u) acc = vadd(acc, sunlight);
+                        L = vadd(acc, light2);
+                    }
+                    light = vadd(v3(0.0f, 0.0f, 0.0f), L);
+                    path_done = true;
+                } else {
+                    a.stack[((size_t)c2_id(A) * stack_levels + (level - 1)) * a.nthreads + gtid] = material;   // albedo of surface level+1
+                    sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
+                    new_level = level + 1u; begin_level = true;
+                }
+            }
+            if (path_done) {   // the path's light; k_accumulate_paths adds the samples of a pixel in order
+                a.pl[A.item] = make_float4(light.x, light.y, light.z, 0.0f);
+                c2_set_phase(A, P2_EMPTY);
+            }
+        }
+        // empty contexts pull the next paths (chunked cursor, see k_persist)
+        if (!exhausted) {
+            const bool wantme = c2_phase(A) == P2_EMPTY && !F.tracing;
+            const uint64_t want = __ballot(wantme);
+            const uint32_t nwant = (uint32_t)__popcll(want);
+            if (nwant) {
+                if (chunk_next >= chunk_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(a.cursor, kChunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    chunk_next = base;
+                    chunk_end = base + kChunk < nitems ? base + kChunk : nitems;
+                    if (base >= nitems) { exhausted = true; chunk_next = chunk_end = nitems; }
+                    chunk_sb = chunk_next / nwork; chunk_w = chunk_next - chunk_sb * nwork;   // once per chunk
+                }
+                const uint32_t take = min(nwant, chunk_end - chunk_next);
+                const uint32_t first = chunk_next;
+                chunk_next += take;
+                if (wantme) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                    if (rank < take) {
+                        uint32_t sb = chunk_sb, w = chunk_w + rank;
+                        while (w >= nwork) { w -= nwork; sb++; }
+                        uint32_t wgx8 = 0, wgy8 = 0;
+                        bool ok = true;
+                        if (CACHE) {
+                            const uint32_t info = a.pinfo[w];
+                            sfx = a.phx[w]; sfy = a.phy[w]; sfz = a.phz[w];
+                            snormal = info >> 28; wgx8 = info & 0x3FFFu; wgy8 = (info >> 14) & 0x3FFFu;
+                        } else {
+                            PixelId pix = pixel_of_local(f, w);
+                            ok = pix.inside;           // padding pixels of partial tiles carry no path
+                            wgx8 = owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE;
+                            wgy8 = owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE;
+                        }
+                        if (ok) {
+                            A.st = (A.st & 0x80u) | 7u << 8 | P2_EMPTY;   // face id 7: q* hold no table entry of this path
+                            A.item = first + rank; A.lp = w; A.samp = a.sample0 + sb;
+                            const uint32_t seed = (f.seed + A.samp) % (uint32_t)RT_NOISE_BYTES;
+                            const uint32_t by = seed / RT_NOISE_SIZE;
+                            const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
+                            const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
+                            A.sn = sc.noise[ty * RT_NOISE_SIZE + tx] & 0xFFFFu;   // noise_value (r, g); no shadow bits yet
+                            if (CACHE) { new_level = 1; begin_level = true; }
+                            else need_primary = true;
+                        }
+                    }
+                }
+                chunk_w += take;
+                while (chunk_w >= nwork) { chunk_w -= nwork; chunk_sb++; }
+            }
+        }
+        // both rays of a level (:324-330 / :336-342): the shadow ray starts now; the diffuse ray's table entry, first texel
+        // and origin wait in the context's q*/ovox registers and in s_org
+        if (begin_level) {
+            if (COUNT) { c_noise++; c_shadow++; c_dif++; }
+            int ix, iy, iz;
+            const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
+            const uint32_t vox0 = swizzled_index(ix, iy, iz, LB), cidx0 = coarse_index(ix, iy, iz, LOGR);
+            const uint32_t se = A.sn & 0xFFFFu;
+            const float4 sd = a.sun_lut[2u * se], sl = a.sun_lut[2u * se + 1u];
+            F.lx = sl.x; F.ly = sl.y; F.lz = sl.z;
+            arm(F, sd.x, sd.y, sd.z, sfx, sfy, sfz, ok, vox0, cidx0);
+            // q* still hold the entry (face, se) of the path's previous level; a new path carries face id 7
+            if (snormal != c2_face(A)) {
+                const uint32_t di = 4u * ((snormal << 16) | se);
+                const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
+                A.qdx = d2.x; A.qdy = d2.y; A.qdz = d2.z; A.qlx = dl.x; A.qly = dl.y; A.qlz = dl.z;
+            }
+            const uint32_t id = c2_id(A);
+            s_org[id][0][threadIdx.x] = sfx; s_org[id][1][threadIdx.x] = sfy; s_org[id][2][threadIdx.x] = sfz;
+            A.ovox = vox0 | (ok ? 0x80000000u : 0u); A.ocidx = cidx0;
+            A.st = P2_SHADOW | new_level << 2 | (A.st & 0x80u) | snormal << 8;
+        }
+        // primary ray of the pixel (:296-315), CACHE=false only
+        if (!CACHE && need_primary) {
+            PixelId pix = pixel_of_local(f, A.lp);
+            vec3 ro, rd;
+            primary_ray(f, pix.px, pix.py, &ro, &rd);
+            int ix, iy, iz;
+            const bool ok = wrap_texel(ro, (float)R, &ix, &iy, &iz);
+            const vec3 d = vnormalize(rd);                                                               // :83
+            F.lx = 1.0f / rtm_abs(d.x); F.ly = 1.0f / rtm_abs(d.y); F.lz = 1.0f / rtm_abs(d.z);           // :88
+            arm(F, d.x, d.y, d.z, ro.x, ro.y, ro.z, ok, swizzled_index(ix, iy, iz, LB), coarse_index(ix, iy, iz, LOGR));
+            c2_set_phase(A, P2_PRIMARY);
+            if (COUNT) c_prim++;
+        }
+        mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
+        shA = __ballot(c2_phase(A) == P2_SHADOW); shB = __ballot(c2_phase(B) == P2_SHADOW);
+        pkA = __ballot(c2_parks(A, exhausted)); pkB = __ballot(c2_parks(B, exhausted));
+    }
+    if (COUNT) {
+        DevCounters* cn = a.counters;
+        const unsigned long long rays = c_prim + c_shadow + c_dif;
+        wave_add(&cn->rays, rays); wave_add(&cn->rays_primary, c_prim); wave_add(&cn->rays_shadow, c_shadow);
+        wave_add(&cn->rays_diffuse, c_dif); wave_add(&cn->iterations, c_iter); wave_add(&cn->minefield_fetches, rays + c_iter);
+        wave_add(&cn->hits, c_hits); wave_add(&cn->material_fetches, c_hits); wave_add(&cn->sky_exits, c_sky);
+        wave_add(&cn->limit_exits, c_limit); wave_add(&cn->border_fetches, c_border); wave_add(&cn->noise_fetches, c_noise);
+        wave_add(&cn->pixels, c_pix);
+        if (lane == 0) {
+            atomicAdd(&cn->dbg_loop_iters, d_iters); atomicAdd(&cn->dbg_s_execs, d_sx); atomicAdd(&cn->dbg_f_execs, d_fx);
+            atomicAdd(&cn->dbg_s_lanes, d_sl); atomicAdd(&cn->dbg_f_lanes, d_fl); atomicAdd(&cn->dbg_passes, d_pass);
+            atomicAdd(&cn->dbg_pass_lanes, d_pl); atomicAdd(&cn->dbg_sky_lanes, d_sky);
+        }
+    }
+}
+
 // acc[pixel] (+)= the batch's samples of that pixel, in sample order (deterministic fp32 sum; raytrace.comp has one
 // sample per frame, the sum over frames is the build's spp extension).
 template <bool CACHE>
@@ -568,9 +1011,13 @@ hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, con
 
 template <int LOGR>
 static void launch_persist_logr(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
-                                dim3 grid, dim3 block, hipStream_t st) {
+                                int version, dim3 grid, dim3 block, hipStream_t st) {
     const bool lrz = f.lr_zero != 0;
-#define RT_LAUNCH_PERSIST(L, C, K) hipLaunchKernelGGL((k_persist<LOGR, L, C, K>), grid, block, 0, st, sc, f, pl, a)
+#define RT_LAUNCH_PERSIST(L, C, K)                                                                        \
+    do {                                                                                                  \
+        if (version == 2) hipLaunchKernelGGL((k_persist2<LOGR, L, C, K>), grid, block, 0, st, sc, f, pl, a); \
+        else hipLaunchKernelGGL((k_persist<LOGR, L, C, K>), grid, block, 0, st, sc, f, pl, a);            \
+    } while (0)
     if (lrz) {
         if (count) { if (cache) RT_LAUNCH_PERSIST(true, true, true); else RT_LAUNCH_PERSIST(true, true, false); }
         else       { if (cache) RT_LAUNCH_PERSIST(true, false, true); else RT_LAUNCH_PERSIST(true, false, false); }
@@ -582,11 +1029,11 @@ static void launch_persist_logr(const Scene& sc, const Frame& f, const Planes& p
 }
 
 hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
-                          int nworkgroups, hipStream_t st) {
+                          int version, int nworkgroups, hipStream_t st) {
     dim3 grid(nworkgroups), block(1024);
-    if (f.logr == 8) launch_persist_logr<8>(sc, f, pl, a, count, cache, grid, block, st);
-    else if (f.logr == 9) launch_persist_logr<9>(sc, f, pl, a, count, cache, grid, block, st);
-    else if (f.logr == 10) launch_persist_logr<10>(sc, f, pl, a, count, cache, grid, block, st);
+    if (f.logr == 8) launch_persist_logr<8>(sc, f, pl, a, count, cache, version, grid, block, st);
+    else if (f.logr == 9) launch_persist_logr<9>(sc, f, pl, a, count, cache, version, grid, block, st);
+    else if (f.logr == 10) launch_persist_logr<10>(sc, f, pl, a, count, cache, version, grid, block, st);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

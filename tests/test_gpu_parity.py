@@ -15,7 +15,7 @@ from tests import scenes
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [abi.RT_KERNEL_MEGA, abi.RT_KERNEL_WAVEFRONT, abi.RT_KERNEL_PERSISTENT]
+KERNELS = [abi.RT_KERNEL_MEGA, abi.RT_KERNEL_WAVEFRONT, abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2]
 RMS_TOL = 1e-4  # BASELINE.json north_star: per-pixel RMS error <= 1e-4 vs the CPU reference
 
 
@@ -383,6 +383,8 @@ def region512(native_built):
 
 @pytest.mark.parametrize("kernel,flags", [(abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS),
                                           (abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_CACHE_PRIMARY),
+                                          (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_COUNTERS),
+                                          (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_CACHE_PRIMARY),
                                           (abi.RT_KERNEL_MEGA, abi.RT_FLAG_COUNTERS)])
 @pytest.mark.parametrize("pose", [
     dict(origin=(-60.0, -256.0, 110.0), heading=np.pi / 2, pitch=-0.05, sun=0.0, lr=(0, 0, 0)),
