@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4)
-    ap.add_argument("--kernel", choices=["persistent", "persistent2", "wavefront", "mega"], default="persistent")
+    ap.add_argument("--kernel", choices=["default", "persistent", "persistent2", "wavefront", "mega"], default="default")
     ap.add_argument("--no-cache-primary", dest="cache_primary", action="store_false",
                     help="re-trace the (seed-independent) primary ray for every sample, like spp reference frames would")
     ap.set_defaults(cache_primary=True)
@@ -114,6 +114,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     W, H, SPP, D = args.width, args.height, args.spp, args.depth
+    if args.kernel == "default":   # what RT_KERNEL_DEFAULT resolves to for this workload (rt_create); named so the report says which
+        tiles = ((args.width + 7) // 8) * ((args.height + 7) // 8)
+        args.kernel = "persistent2" if (tiles + world - 1) // world * 64 * args.spp >= (24 << 20) else "persistent"
     kernel = {"persistent": abi.RT_KERNEL_PERSISTENT, "persistent2": abi.RT_KERNEL_PERSISTENT2, "wavefront": abi.RT_KERNEL_WAVEFRONT,
               "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0

@@ -77,7 +77,7 @@ struct RtContext {
     float4* pacc = nullptr;
     float4* ppl = nullptr;
     uint32_t persist_batch = 1;
-    uint32_t persist_threshold = 0, persist_rmin = 16;   // threshold 0 = the kernel version's default
+    uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
     int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2)
     rtd::DevCounters* d_counters = nullptr;
     uint64_t host_noise_base = 0, host_frames = 0;
@@ -287,8 +287,15 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     c->region = cfg->region;
     c->logr = cfg->region == 256 ? 8 : (cfg->region == 512 ? 9 : 10);
     c->vox = (size_t)cfg->region * cfg->region * cfg->region;
-    c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PERSISTENT : cfg->kernel;
-    if (c->kernel == RT_KERNEL_PERSISTENT2) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 2; }   // same pipeline, other path kernel
+    {
+        // RT_KERNEL_DEFAULT: the two-paths-per-lane kernel wins once a launch has paths to keep both contexts of every lane
+        // busy (measured crossover at 1920x1080: spp 12-16, i.e. ~24 M pixel-samples per context); below that the
+        // one-path kernel has the shorter ramp-up and tail
+        const uint64_t tiles = ((uint64_t)(cfg->width + 7) / 8) * ((uint64_t)(cfg->height + 7) / 8);
+        const uint64_t samples = (tiles + cfg->tile_world - 1) / cfg->tile_world * 64u * (uint64_t)cfg->spp;
+        c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? (samples >= (24ull << 20) ? RT_KERNEL_PERSISTENT2 : RT_KERNEL_PERSISTENT) : cfg->kernel;
+        if (c->kernel == RT_KERNEL_PERSISTENT2) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 2; }   // same pipeline, other path kernel
+    }
     RT_HIP_CREATE(hipSetDevice(c->device));
     hipDeviceProp_t prop;
     RT_HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
@@ -340,7 +347,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
-    if (c->persist_threshold == 0) c->persist_threshold = c->persist_version == 2 ? 48u : 32u;   // measured optima
+    if (c->persist_threshold == 0) c->persist_threshold = c->persist_version == 2 ? 40u : 32u;   // measured optima
     if (c->kernel == RT_KERNEL_PERSISTENT) {
         RT_HIP_CREATE(dev_alloc(c, &c->pcursor, 2));
         RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)2 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));

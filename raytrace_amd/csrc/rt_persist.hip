@@ -703,78 +703,13 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
         }
     };
 
-    // wave-uniform lane masks.  sh* = context is on its shadow ray; pk* = a context that parks when its ray ends (diffuse or
-    // primary ray in flight, or no path while paths are left)
-    uint64_t mA = 0, mB = 0, shA = 0, shB = 0, pkA = ~0ull, pkB = ~0ull;
-    for (;;) {
-        uint64_t need = (~mA & pkA) | (~mB & pkB);
-        if ((uint32_t)__popcll(need) < threshold && (mA | mB) != 0ull) {
-            // ---- step loop ----------------------------------------------------------------------------------------
-            do {
-                // fetches of both contexts first (:106 for a fresh ray, :137 otherwise), so their latencies overlap
-                const uint32_t bA = LOGR == 8 ? A.r.vox >> 6 : A.r.cidx, bB = LOGR == 8 ? B.r.vox >> 6 : B.r.cidx;
-                const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
-                const uint32_t wA = s_nib[bA >> 1], wB = s_nib[bB >> 1];
-                uint32_t stA = (wA >> ((bA & 1u) << 2)) & 15u, stB = (wB >> ((bB & 1u) << 2)) & 15u;
-                const bool gA = A.r.tracing && stA == kNibMixed, gB = B.r.tracing && stB == kNibMixed;
-                uint8_t byA = 0, byB = 0;
-                if (gA) byA = sc.mine[A.r.vox];
-                if (gB) byB = sc.mine[B.r.vox];
-                if (gA) stA = byA;
-                if (gB) stB = byB;
-                if (COUNT) {
-                    const uint32_t nA = (uint32_t)__popcll(mA), nB = (uint32_t)__popcll(mB);
-                    d_iters++; if (nA) { d_sx++; d_sl += nA; } if (nB) { d_fx++; d_fl += nB; }
-                }
-                if (A.r.tracing) advance(A.r, stA);
-                if (B.r.tracing) advance(B.r, stB);
-                mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
-                const uint64_t rA = shA & ~mA, rB = shB & ~mB;
-                const uint32_t nre = (uint32_t)__popcll(rA) + (uint32_t)__popcll(rB);
-                if (nre >= rmin || ((mA | mB) == 0ull && nre != 0u)) {
-                    rearm(A); rearm(B);
-                    mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
-                    shA &= ~rA; shB &= ~rB; pkA |= rA; pkB |= rB;
-                }
-                need = (~mA & pkA) | (~mB & pkB);
-            } while ((uint32_t)__popcll(need) < threshold && (mA | mB) != 0ull);
-            continue;
-        }
-        if (need == 0ull) {
-            // no ray in flight and no context parked: only finished shadow rays can be left
-            const uint64_t rA = shA & ~mA, rB = shB & ~mB;
-            if ((rA | rB) == 0ull) break;             // ... or nothing at all: the wave is done
-            rearm(A); rearm(B);
-            mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
-            shA &= ~rA; shB &= ~rB; pkA |= rA; pkB |= rB;
-            continue;
-        }
-
-        // =========================== transition pass ===========================================================
-        // The pass serves context A.  Lanes whose parked context is B (and whose A is not parked) swap the two.
-        {
-            const bool parkA = !A.r.tracing && c2_parks(A, exhausted);
-            const bool parkB = !B.r.tracing && c2_parks(B, exhausted);
-            if (parkB && !parkA) {
-                swap32(A.r.px, B.r.px); swap32(A.r.py, B.r.py); swap32(A.r.pz, B.r.pz);
-                swap32(A.r.ndx, B.r.ndx); swap32(A.r.ndy, B.r.ndy); swap32(A.r.ndz, B.r.ndz);
-                swap32(A.r.lx, B.r.lx); swap32(A.r.ly, B.r.ly); swap32(A.r.lz, B.r.lz);
-                swap32(A.r.ux, B.r.ux); swap32(A.r.uy, B.r.uy); swap32(A.r.uz, B.r.uz);
-                swap32(A.r.vox, B.r.vox); if (LOGR != 8) swap32(A.r.cidx, B.r.cidx);
-                swap32(A.r.nk, B.r.nk); swap32(A.r.axis, B.r.axis);
-                swapb(A.r.tracing, B.r.tracing);
-                if (!LRZ) swapb(A.r.valid, B.r.valid);
-                if (COUNT) swapb(A.r.fresh_invalid, B.r.fresh_invalid);
-                swap32(A.qdx, B.qdx); swap32(A.qdy, B.qdy); swap32(A.qdz, B.qdz);
-                swap32(A.qlx, B.qlx); swap32(A.qly, B.qly); swap32(A.qlz, B.qlz);
-                swap32(A.ovox, B.ovox); if (LOGR != 8) swap32(A.ocidx, B.ocidx);
-                swap32(A.st, B.st); swap32(A.item, B.item); swap32(A.sn, B.sn);
-                if (!CACHE) { swap32(A.lp, B.lp); swap32(A.samp, B.samp); }
-            }
-        }
-        RaySlot2& F = A.r;
-        const uint32_t phaseA = c2_phase(A);
-        const bool mine = !F.tracing && (phaseA == P2_DIF || phaseA == P2_PRIMARY);
+    // =========================== transition pass ===========================================================
+    // One pass serves ONE of the two contexts of every lane (C = A or B): two instantiations of the same code, so no
+    // register shuffling between the contexts is needed.
+    auto pass = [&](Ctx2& C) {
+        RaySlot2& F = C.r;
+        const uint32_t phaseC = c2_phase(C);
+        const bool mine = !F.tracing && (phaseC == P2_DIF || phaseC == P2_PRIMARY);
         if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); }
         bool begin_level = false, need_primary = false;
         uint32_t new_level = 0;
@@ -796,11 +731,11 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
             if (COUNT) tally(F);
             bool path_done = false;
             vec3 light = v3(0, 0, 0);
-            if (!CACHE && phaseA == P2_PRIMARY) {
-                PixelId pix = pixel_of_local(f, A.lp);
+            if (!CACHE && phaseC == P2_PRIMARY) {
+                PixelId pix = pixel_of_local(f, C.lp);
                 vec3 pstart, pdir;
                 primary_ray(f, pix.px, pix.py, &pstart, &pdir);
-                if (A.samp == 0u) {
+                if (C.samp == 0u) {
                     store_primary_planes(pl, pix.out_index, f, pdir, air, nrm, material, v3(hx, hy, hz));
                     if (COUNT) c_pix++;
                 }
@@ -811,21 +746,21 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
                     path_done = true;
                 } else {
                     sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
-                    new_level = 1; A.sn &= 0xFFFFu; begin_level = true;
+                    new_level = 1; C.sn &= 0xFFFFu; begin_level = true;
                 }
             } else {
                 // a level ended: its shadow result is already in the shadow bits (rearm); now the diffuse result
-                const uint32_t level = c2_level(A), sunbits = A.sn >> 16;
+                const uint32_t level = c2_level(C), sunbits = C.sn >> 16;
                 if (air || level == D) {
                     const vec3 sunlight = ld3(f.sunlight);
                     vec3 sky = v3(0, 0, 0);
-                    if (air) { const float4 t = a.dif_lut[4u * ((c2_face(A) << 16) | (A.sn & 0xFFFFu)) + 3u]; sky = v3(t.x, t.y, t.z); }   // :331-332 / :343-345, tabulated
+                    if (air) { const float4 t = a.dif_lut[4u * ((c2_face(C) << 16) | (C.sn & 0xFFFFu)) + 3u]; sky = v3(t.x, t.y, t.z); }   // :331-332 / :343-345, tabulated
                     // L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
                     vec3 L = v3(0.0f, 0.0f, 0.0f);
                     if (sunbits >> (level - 1) & 1u) L = vadd(L, sunlight);
                     if (air) L = vadd(L, sky);
                     for (uint32_t j = level - 1; j >= 1u; j--) {
-                        const uint32_t pm = a.stack[((size_t)c2_id(A) * stack_levels + (j - 1)) * a.nthreads + gtid];
+                        const uint32_t pm = a.stack[((size_t)c2_id(C) * stack_levels + (j - 1)) * a.nthreads + gtid];
                         vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
                         light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
                         vec3 acc = v3(0.0f, 0.0f, 0.0f);
@@ -835,19 +770,19 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
                     light = vadd(v3(0.0f, 0.0f, 0.0f), L);
                     path_done = true;
                 } else {
-                    a.stack[((size_t)c2_id(A) * stack_levels + (level - 1)) * a.nthreads + gtid] = material;   // albedo of surface level+1
+                    a.stack[((size_t)c2_id(C) * stack_levels + (level - 1)) * a.nthreads + gtid] = material;   // albedo of surface level+1
                     sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
                     new_level = level + 1u; begin_level = true;
                 }
             }
             if (path_done) {   // the path's light; k_accumulate_paths adds the samples of a pixel in order
-                a.pl[A.item] = make_float4(light.x, light.y, light.z, 0.0f);
-                c2_set_phase(A, P2_EMPTY);
+                a.pl[C.item] = make_float4(light.x, light.y, light.z, 0.0f);
+                c2_set_phase(C, P2_EMPTY);
             }
         }
         // empty contexts pull the next paths (chunked cursor, see k_persist)
         if (!exhausted) {
-            const bool wantme = c2_phase(A) == P2_EMPTY && !F.tracing;
+            const bool wantme = c2_phase(C) == P2_EMPTY && !F.tracing;
             const uint64_t want = __ballot(wantme);
             const uint32_t nwant = (uint32_t)__popcll(want);
             if (nwant) {
@@ -881,13 +816,13 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
                             wgy8 = owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE;
                         }
                         if (ok) {
-                            A.st = (A.st & 0x80u) | 7u << 8 | P2_EMPTY;   // face id 7: q* hold no table entry of this path
-                            A.item = first + rank; A.lp = w; A.samp = a.sample0 + sb;
-                            const uint32_t seed = (f.seed + A.samp) % (uint32_t)RT_NOISE_BYTES;
+                            C.st = (C.st & 0x80u) | 7u << 8 | P2_EMPTY;   // face id 7: q* hold no table entry of this path
+                            C.item = first + rank; C.lp = w; C.samp = a.sample0 + sb;
+                            const uint32_t seed = (f.seed + C.samp) % (uint32_t)RT_NOISE_BYTES;
                             const uint32_t by = seed / RT_NOISE_SIZE;
                             const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
                             const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
-                            A.sn = sc.noise[ty * RT_NOISE_SIZE + tx] & 0xFFFFu;   // noise_value (r, g); no shadow bits yet
+                            C.sn = sc.noise[ty * RT_NOISE_SIZE + tx] & 0xFFFFu;   // noise_value (r, g); no shadow bits yet
                             if (CACHE) { new_level = 1; begin_level = true; }
                             else need_primary = true;
                         }
@@ -904,24 +839,24 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
             int ix, iy, iz;
             const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
             const uint32_t vox0 = swizzled_index(ix, iy, iz, LB), cidx0 = coarse_index(ix, iy, iz, LOGR);
-            const uint32_t se = A.sn & 0xFFFFu;
+            const uint32_t se = C.sn & 0xFFFFu;
             const float4 sd = a.sun_lut[2u * se], sl = a.sun_lut[2u * se + 1u];
             F.lx = sl.x; F.ly = sl.y; F.lz = sl.z;
             arm(F, sd.x, sd.y, sd.z, sfx, sfy, sfz, ok, vox0, cidx0);
             // q* still hold the entry (face, se) of the path's previous level; a new path carries face id 7
-            if (snormal != c2_face(A)) {
+            if (snormal != c2_face(C)) {
                 const uint32_t di = 4u * ((snormal << 16) | se);
                 const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
-                A.qdx = d2.x; A.qdy = d2.y; A.qdz = d2.z; A.qlx = dl.x; A.qly = dl.y; A.qlz = dl.z;
+                C.qdx = d2.x; C.qdy = d2.y; C.qdz = d2.z; C.qlx = dl.x; C.qly = dl.y; C.qlz = dl.z;
             }
-            const uint32_t id = c2_id(A);
+            const uint32_t id = c2_id(C);
             s_org[id][0][threadIdx.x] = sfx; s_org[id][1][threadIdx.x] = sfy; s_org[id][2][threadIdx.x] = sfz;
-            A.ovox = vox0 | (ok ? 0x80000000u : 0u); A.ocidx = cidx0;
-            A.st = P2_SHADOW | new_level << 2 | (A.st & 0x80u) | snormal << 8;
+            C.ovox = vox0 | (ok ? 0x80000000u : 0u); C.ocidx = cidx0;
+            C.st = P2_SHADOW | new_level << 2 | (C.st & 0x80u) | snormal << 8;
         }
         // primary ray of the pixel (:296-315), CACHE=false only
         if (!CACHE && need_primary) {
-            PixelId pix = pixel_of_local(f, A.lp);
+            PixelId pix = pixel_of_local(f, C.lp);
             vec3 ro, rd;
             primary_ray(f, pix.px, pix.py, &ro, &rd);
             int ix, iy, iz;
@@ -929,9 +864,59 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
             const vec3 d = vnormalize(rd);                                                               // :83
             F.lx = 1.0f / rtm_abs(d.x); F.ly = 1.0f / rtm_abs(d.y); F.lz = 1.0f / rtm_abs(d.z);           // :88
             arm(F, d.x, d.y, d.z, ro.x, ro.y, ro.z, ok, swizzled_index(ix, iy, iz, LB), coarse_index(ix, iy, iz, LOGR));
-            c2_set_phase(A, P2_PRIMARY);
+            c2_set_phase(C, P2_PRIMARY);
             if (COUNT) c_prim++;
         }
+    };
+    // wave-uniform lane masks.  sh* = context is on its shadow ray; pk* = a context that parks when its ray ends (diffuse or
+    // primary ray in flight, or no path while paths are left)
+    uint64_t mA = 0, mB = 0, shA = 0, shB = 0, pkA = ~0ull, pkB = ~0ull;
+    for (;;) {
+        uint64_t needA = ~mA & pkA, needB = ~mB & pkB;
+        if ((uint32_t)__popcll(needA) < threshold && (uint32_t)__popcll(needB) < threshold && (mA | mB) != 0ull) {
+            // ---- step loop ----------------------------------------------------------------------------------------
+            do {
+                // fetches of both contexts first (:106 for a fresh ray, :137 otherwise), so their latencies overlap
+                const uint32_t bA = LOGR == 8 ? A.r.vox >> 6 : A.r.cidx, bB = LOGR == 8 ? B.r.vox >> 6 : B.r.cidx;
+                const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
+                const uint32_t wA = s_nib[bA >> 1], wB = s_nib[bB >> 1];
+                uint32_t stA = (wA >> ((bA & 1u) << 2)) & 15u, stB = (wB >> ((bB & 1u) << 2)) & 15u;
+                const bool gA = A.r.tracing && stA == kNibMixed, gB = B.r.tracing && stB == kNibMixed;
+                uint8_t byA = 0, byB = 0;
+                if (gA) byA = sc.mine[A.r.vox];
+                if (gB) byB = sc.mine[B.r.vox];
+                if (gA) stA = byA;
+                if (gB) stB = byB;
+                if (COUNT) {
+                    const uint32_t nA = (uint32_t)__popcll(mA), nB = (uint32_t)__popcll(mB);
+                    d_iters++; if (nA) { d_sx++; d_sl += nA; } if (nB) { d_fx++; d_fl += nB; }
+                }
+                if (A.r.tracing) advance(A.r, stA);
+                if (B.r.tracing) advance(B.r, stB);
+                mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
+                const uint64_t rA = shA & ~mA, rB = shB & ~mB;
+                const uint32_t nre = (uint32_t)__popcll(rA) + (uint32_t)__popcll(rB);
+                if (nre >= rmin || ((mA | mB) == 0ull && nre != 0u)) {
+                    rearm(A); rearm(B);
+                    mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
+                    shA &= ~rA; shB &= ~rB; pkA |= rA; pkB |= rB;
+                }
+                needA = ~mA & pkA; needB = ~mB & pkB;
+            } while ((uint32_t)__popcll(needA) < threshold && (uint32_t)__popcll(needB) < threshold && (mA | mB) != 0ull);
+            continue;
+        }
+        if ((needA | needB) == 0ull) {
+            // no ray in flight and no context parked: only finished shadow rays can be left
+            const uint64_t rA = shA & ~mA, rB = shB & ~mB;
+            if ((rA | rB) == 0ull) break;             // ... or nothing at all: the wave is done
+            rearm(A); rearm(B);
+            mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
+            shA &= ~rA; shB &= ~rB; pkA |= rA; pkB |= rB;
+            continue;
+        }
+
+        // serve the context type with more parked lanes
+        if ((uint32_t)__popcll(needA) >= (uint32_t)__popcll(needB)) pass(A); else pass(B);
         mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
         shA = __ballot(c2_phase(A) == P2_SHADOW); shB = __ballot(c2_phase(B) == P2_SHADOW);
         pkA = __ballot(c2_parks(A, exhausted)); pkB = __ballot(c2_parks(B, exhausted));
