@@ -434,3 +434,32 @@ def test_region_1024_matches_oracle(blue_noise, native_built):
         gpu = ctx.readback_all()
         gcn = ctx.counters()
     _compare(gpu, cpu, gcn, ccn)
+
+
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2])
+@pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 3, 2), (5, 3, 2, 4), (9, 17, 1, abi.MAX_DEPTH), (24, 16, 37, 3)])
+def test_edge_shapes_match_oracle(procedural_region, blue_noise, kernel, W, H, spp, depth):
+    """Frames smaller than one tile / one wave, the maximum depth, and more samples than lanes."""
+    mats, mine = procedural_region
+    u = _uniforms(seed=77)
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    for flags in (abi.RT_FLAG_COUNTERS, abi.RT_FLAG_CACHE_PRIMARY):
+        gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=flags)
+        if flags & abi.RT_FLAG_CACHE_PRIMARY:
+            _compare(gpu, cpu)
+        else:
+            _compare(gpu, cpu, gcn, ccn)
+
+
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2])
+def test_sample_batches_accumulate_in_order(procedural_region, blue_noise, kernel, monkeypatch):
+    """spp larger than one launch holds: RT_PERSIST_BATCH forces 4 launches of 3 + 3 + 3 + 1 samples; the per-pixel sum must
+    still run in sample order (same bits as one launch and as the oracle)."""
+    mats, mine = procedural_region
+    u = _uniforms(seed=5)
+    W, H, spp, depth = 72, 40, 10, 3
+    cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    monkeypatch.setenv("RT_PERSIST_BATCH", "3")
+    for flags in (0, abi.RT_FLAG_CACHE_PRIMARY):
+        gpu, _ = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=flags)
+        _compare(gpu, cpu)
