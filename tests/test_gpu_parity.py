@@ -423,17 +423,22 @@ def test_region_1024_matches_oracle(blue_noise, native_built):
     """Config C5's scene size: 1024^3 (1 GiB minefield + 4 GiB materials — larger than the 256 MiB Infinity Cache)."""
     mats, mine = world.generate_region(world.DEFAULT_SEED, region=1024)
     u = po.camera_uniforms((-120.0, -512.0, 400.0), np.pi / 2, -0.3, 0.0, 1)
-    W, H, spp, depth = 96, 64, 1, 2
+    W, H, spp, depth = 96, 64, 2, 3
     cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth, region=1024)
-    cfg = render.make_config(W, H, spp=spp, depth=depth, flags=abi.RT_FLAG_COUNTERS, region=1024)
-    with render.Context(cfg) as ctx:
-        ctx.upload_world(mats, mine)
-        ctx.upload_noise(blue_noise)
-        ctx.draw_frame(u)
-        ctx.sync()
-        gpu = ctx.readback_all()
-        gcn = ctx.counters()
-    _compare(gpu, cpu, gcn, ccn)
+    for kernel, flags in ((abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS), (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_COUNTERS),
+                          (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_CACHE_PRIMARY)):
+        cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=kernel, flags=flags, region=1024)
+        with render.Context(cfg) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(u)
+            ctx.sync()
+            gpu = ctx.readback_all()
+            gcn = ctx.counters()
+        if flags & abi.RT_FLAG_CACHE_PRIMARY:
+            _compare(gpu, cpu)
+        else:
+            _compare(gpu, cpu, gcn, ccn)
 
 
 @pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2])
