@@ -28,7 +28,7 @@ CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-mfma", "-ffp-contract=off", "-fno-f
 
 AMD_SRCS = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "rt_persist.hip"), os.path.join(CSRC, "rt_post.hip"),
             os.path.join(CSRC, "rt_api.hip")]
-AMD_DEPS = AMD_SRCS + [os.path.join(CSRC, "rt_device.hpp"), os.path.join(CSRC, "rt_kernels.hpp"),
+AMD_DEPS = AMD_SRCS + [os.path.join(CSRC, "rt_device.hpp"), os.path.join(CSRC, "rt_kernels.hpp"), os.path.join(CSRC, "rt_dda.hpp"),
                        os.path.join(INC, "rt_abi.h"), os.path.join(INC, "rt_math.h")]
 HOST_SRCS = [os.path.join(HOST, f) for f in ("world.cpp", "chunk_storage.cpp", "terrain_upload.cpp", "render.cpp", "host_capi.cpp")]
 HOST_DEPS = HOST_SRCS + [os.path.join(HOST, f) for f in ("world.hpp", "render.hpp", "chunk_storage.hpp", "terrain_upload.hpp")] + [os.path.join(INC, "rt_abi.h")]

@@ -79,6 +79,7 @@ struct RtContext {
     uint32_t persist_batch = 1;
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
     int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2)
+    int primary_version = 2;      // 1 = k_primary (thread per pixel), 2 = k_primary2 (nibble map in LDS); RT_PRIMARY_V
     rtd::DevCounters* d_counters = nullptr;
     uint64_t host_noise_base = 0, host_frames = 0;
 
@@ -345,6 +346,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     }
 
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
+    if (const char* s = getenv("RT_PRIMARY_V")) { int v = atoi(s); if (v == 1 || v == 2) c->primary_version = v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
     if (c->persist_threshold == 0) c->persist_threshold = c->persist_version == 2 ? 40u : 32u;   // measured optima
@@ -493,7 +495,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
             rtd::PrimaryArgs pr{};
             pr.phx = ctx->phx; pr.phy = ctx->phy; pr.phz = ctx->phz; pr.pinfo = ctx->pinfo;
             pr.worklist = ctx->worklist; pr.wl_count = ctx->pcursor + 1; pr.acc = ctx->pacc; pr.counters = ctx->d_counters;
-            e = rtd::launch_primary(scene_of(ctx), f, planes_of(ctx), pr, count, ctx->stream);
+            e = rtd::launch_primary(scene_of(ctx), f, planes_of(ctx), pr, count, ctx->primary_version, ctx->num_cus, ctx->stream);
         }
         if (e == hipSuccess && ctx->cfg.depth >= 1) {
             LaunchTimer t(ctx, 1);

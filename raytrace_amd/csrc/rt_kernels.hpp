@@ -80,7 +80,8 @@ hipError_t launch_sphere_lut(float4* lut, hipStream_t st);
 hipError_t launch_dif_lut(const float4* sphere, float4* lut, hipStream_t st);
 hipError_t launch_sun_lut(const Frame& f, float4* lut, hipStream_t st);
 hipError_t launch_sky_lut(const Frame& f, float4* dif_lut, hipStream_t st);
-hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count, hipStream_t st);
+hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count,
+                          int version /* 1 = k_primary, 2 = k_primary2 */, int nworkgroups, hipStream_t st);
 hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
                           int version /* 1 = k_persist, 2 = k_persist2 */, int nworkgroups, hipStream_t st);
 

@@ -24,6 +24,7 @@
 
 #include <type_traits>
 
+#include "rt_dda.hpp"
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
 
@@ -135,10 +136,117 @@ __global__ __launch_bounds__(256) void k_primary(Scene sc, Frame f, Planes pl, P
 }
 
 // =====================================================================================================
+// k_primary2 — the same prepass on the persistent machinery
+// =====================================================================================================
+// One 1024-thread workgroup per CU with the nibble map in LDS; every wave walks whole 8x8 tiles (lane = pixel, so the
+// wave's rays are coherent and end within a few steps of each other) with the stepped ray of rt_dda.hpp: ~70 % of the
+// fetches are answered from LDS instead of a dependent global byte load per step.  Results as k_primary.
+template <int LOGR, bool LRZ, bool COUNT>
+__global__ __launch_bounds__(1024) void k_primary2(Scene sc, Frame f, Planes pl, PrimaryArgs a) {
+    __shared__ uint32_t s_coarse[kCoarseWords];
+    __shared__ uint32_t s_cnt[16], s_off[17];   // worklist append: pixels queued by each wave this round, their slot offsets
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.coarse);
+        uint4* dst = reinterpret_cast<uint4*>(s_coarse);
+        for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
+    constexpr int R = 1 << LOGR, LB = LOGR - 2;
+    const float half = (float)R / 2;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * 1024u + threadIdx.x) >> 6, nwaves = gridDim.x * 16u;
+    unsigned long long c_prim = 0, c_pix = 0, c_border = 0;
+    RayTally tl;
+    // All waves of the workgroup run the same number of rounds (the append below has two barriers per round); a wave whose
+    // tile index is past the end carries no pixels in that round.
+    const uint32_t nrounds = ((uint32_t)f.ntiles_local + nwaves - 1u) / nwaves;
+    for (uint32_t round = 0; round < nrounds; round++) {
+        const uint32_t tile = round * nwaves + wave;
+        const uint32_t lp = tile * 64u + lane;
+        PixelId pix = pixel_of_local(f, lp);
+        if (tile >= (uint32_t)f.ntiles_local) pix.inside = false;
+        RaySlot2 r;
+        r.tracing = false; r.valid = true; r.fresh_invalid = false; r.nk = PX_HIT << 16; r.axis = 2u; r.vox = r.cidx = 0u;
+        r.px = r.py = r.pz = r.ndx = r.ndy = r.ndz = r.lx = r.ly = r.lz = r.ux = r.uy = r.uz = 0.0f;
+        vec3 start = v3(0, 0, 0), dir = v3(0, 0, 1);
+        if (pix.inside) {
+            primary_ray(f, pix.px, pix.py, &start, &dir);
+            const vec3 d = vnormalize(dir);                                                          // raytrace.comp:83
+            r.lx = 1.0f / rtm_abs(d.x); r.ly = 1.0f / rtm_abs(d.y); r.lz = 1.0f / rtm_abs(d.z);       // :88
+            int ix, iy, iz;
+            const bool ok = wrap_texel(start, (float)R, &ix, &iy, &iz);
+            dda_arm<LOGR, LRZ, COUNT>(r, d.x, d.y, d.z, start.x, start.y, start.z, ok, swizzled_index(ix, iy, iz, LB),
+                                      coarse_index(ix, iy, iz, LOGR), f, half, s_nib, sc, c_border);
+        }
+        while (__ballot(r.tracing)) {
+            if (r.tracing) dda_advance<LOGR, LRZ, COUNT, false>(r, dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border);
+        }
+        bool queue = false;
+        vec3 qpos = v3(0, 0, 0);
+        uint32_t qnormal = 0;
+        if (pix.inside) {
+            const uint32_t kind = r2_kind(r);
+            const bool air = kind == PX_AIR;
+            const uint32_t nrm = r.axis == 0 ? (r.ndx < 0.0f ? 1u : 0u) : (r.axis == 1 ? (r.ndy < 0.0f ? 3u : 2u) : (r.ndz < 0.0f ? 5u : 4u));
+            uint32_t material = 0;
+            if (kind == PX_HIT && (LRZ || r.valid)) material = sc.mat[r.vox];   // the hit texel is the texel of the last fetch (:150-154)
+            float hx = r.px, hy = r.py, hz = r.pz;
+            if (kind == PX_SPECIAL) { hx = hy = hz = __builtin_nanf(""); }
+            const float off = 0.001f;                                           // :166-180
+            if (nrm == 0) hx += off; else if (nrm == 1) hx -= off;
+            else if (nrm == 2) hy += off; else if (nrm == 3) hy -= off;
+            else if (nrm == 4) hz += off; else hz -= off;
+            if (COUNT) { c_prim++; c_pix++; dda_tally<LOGR>(r, tl); }
+            store_primary_planes(pl, pix.out_index, f, dir, air, nrm, material, v3(hx, hy, hz));
+            if (air || f.depth < 1) {
+                // every sample of this pixel has the same light (no noise is read): sum it spp times like the shader's
+                // spp frames would, then store
+                vec3 light = v3(0.0f, 0.0f, 0.0f);
+                if (air) light = sample_sky(dir, ld3(f.sunangle), ld3(f.sunlight), true);            // raytrace.comp:321-322
+                vec3 sum = v3(0.0f, 0.0f, 0.0f);
+                for (int s = 0; s < f.spp; s++) sum = vadd(sum, light);
+                a.acc[lp] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+            } else {
+                queue = true;
+                qpos = v3(hx, hy, hz); qnormal = nrm;
+            }
+        }
+        // worklist append: ONE atomic per workgroup and round (a single counter word saturates near 90 returning atomics
+        // per microsecond — one per wave made the append, not the tracing, the bound of this kernel), slots ballot-ranked
+        const uint64_t m = __ballot(queue);
+        const uint32_t wiw = threadIdx.x >> 6;
+        if (lane == 0) s_cnt[wiw] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (uint32_t i = 0; i < 16u; i++) { s_off[i] = total; total += s_cnt[i]; }
+            const uint32_t base = total ? atomicAdd(a.wl_count, total) : 0u;
+            for (uint32_t i = 0; i < 16u; i++) s_off[i] += base;
+        }
+        __syncthreads();
+        if (queue) {
+            const uint32_t w = s_off[wiw] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            a.worklist[w] = lp;
+            a.phx[w] = qpos.x; a.phy[w] = qpos.y; a.phz[w] = qpos.z;
+            a.pinfo[w] = (qnormal << 28) | (owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE) << 14 |
+                         (owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE);
+        }
+    }
+    if (COUNT) {
+        DevCounters* cn = a.counters;
+        c_border += tl.border;
+        wave_add(&cn->rays, c_prim); wave_add(&cn->rays_primary, c_prim); wave_add(&cn->iterations, tl.iter);
+        wave_add(&cn->minefield_fetches, c_prim + tl.iter); wave_add(&cn->hits, tl.hits); wave_add(&cn->material_fetches, tl.hits);
+        wave_add(&cn->sky_exits, tl.sky); wave_add(&cn->limit_exits, tl.limit); wave_add(&cn->border_fetches, c_border);
+        wave_add(&cn->pixels, c_pix);
+    }
+}
+
+// =====================================================================================================
 // k_persist
 // =====================================================================================================
 enum : uint32_t { PH_EMPTY = 0, PH_PRIMARY = 1, PH_SUN = 2, PH_DIF = 3 };
-enum : uint32_t { PX_AIR = 0, PX_HIT = 1, PX_LIMIT = 2, PX_SPECIAL = 3 };
 
 // Shadow rays depend only on the frame's sun vector and the (noise.r, noise.g) byte pair (raytrace.comp:185-187), so
 // the whole head of trace_ray for them — normalize (trace_sun), normalize again (:83), 1/|d| (:88) — is tabulated once
@@ -525,17 +633,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
 // first (v_swap_b32), so there is one copy of the pass code.
 enum : uint32_t { P2_EMPTY = 0, P2_PRIMARY = 1, P2_SHADOW = 2, P2_DIF = 3 };
 
-// Ray slot of k_persist2.  Register diet (two contexts must fit 128 VGPRs without spilling):
-// * it keeps the NEGATED direction: with lr = 0, q = (d > 0 ? -u : u) (raytrace.comp:94-98,119) is then one v_bfi of u
-//   with the sign of nd (u > 0 inside the region), the position update fma(d, t, p) is fma(-nd, t, p) with a free source
-//   modifier, and RaySlot's three sign words are not needed.  (For d = +0 the sign of q differs from RaySlot's; that axis
-//   has 1/|d| = inf, so its boundary distance is inf either way and is never the minimum.)
-// * nk = iteration count | kind << 16 (kind is written when the ray ends); "fresh" is nk == 0.
-struct RaySlot2 {
-    float px, py, pz, ndx, ndy, ndz, lx, ly, lz, ux, uy, uz;
-    uint32_t vox, cidx, nk, axis;
-    bool tracing, valid, fresh_invalid;   // valid: only the lr != 0 build steps with it; fresh_invalid: counting build only
-};
+// A path context of k_persist2: its ray slot (RaySlot2, rt_dda.hpp), the level's waiting diffuse ray, the path state.
 struct Ctx2 {
     RaySlot2 r;
     // the level's diffuse ray, waiting for the shadow ray to end: table entry (direction, 1/|direction|) in registers, the
@@ -543,7 +641,7 @@ struct Ctx2 {
     float qdx, qdy, qdz, qlx, qly, qlz;
     uint32_t ovox, ocidx;
     // path state: st = phase | level << 2 | id << 7 | face id of the level's surface << 8 (id: which of the lane's two
-    // stack / origin areas the path uses — it travels with the path when the contexts swap);
+    // stack / origin areas the context uses);
     // sn = noise_value texel bytes (r, g) of the path | shadow bits << 16 (bit j-1: shadow ray of level j reached the sky)
     uint32_t st, item, sn, lp, samp;
 };
@@ -556,12 +654,6 @@ __device__ __forceinline__ bool c2_parks(const Ctx2& c, bool exhausted) {   // p
     const uint32_t ph = c.st & 3u;
     return ph == P2_DIF || ph == P2_PRIMARY || (ph == P2_EMPTY && !exhausted);
 }
-__device__ __forceinline__ uint32_t r2_kind(const RaySlot2& r) { return r.nk >> 16; }
-
-__device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swapb(bool& a, bool& b) { const bool t = a; a = b; b = t; }
-
 template <int LOGR, bool LRZ, bool COUNT, bool CACHE>
 __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes pl, PersistArgs a) {
     __shared__ uint32_t s_coarse[kCoarseWords];
@@ -607,88 +699,17 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
                        c_noise = 0, c_pix = 0;
     unsigned long long d_iters = 0, d_sx = 0, d_fx = 0, d_sl = 0, d_fl = 0, d_pass = 0, d_pl = 0, d_sky = 0;   // wave-uniform
 
-    // ---- one DDA step: fetch value `step` already looked up (the arithmetic of k_persist's advance) -----------------
-    auto advance_t = [&](RaySlot2& r, uint32_t step, auto generic_q) {
-        if (!LRZ && !r.valid) step = 0u;
-        if (step == 0u) {
-            // a fresh ray on a 0 has step_size 0 => mod(x,0) = NaN (defined outcome), otherwise a hit
-            r.nk = r.nk == 0u ? (1u | PX_SPECIAL << 16) : (r.nk | PX_HIT << 16);
-            r.tracing = false;
-        } else if (r.nk == (uint32_t)RT_TRACE_LIMIT) {
-            r.nk |= PX_LIMIT << 16; r.tracing = false;                                              // :109 (Q8)
-        } else {
-            const uint32_t sb = (step << 23) + (126u << 23);          // float((1 << step) / 2)
-            const float sz = __builtin_bit_cast(float, sb);
-            const float is = __builtin_bit_cast(float, 0x7F000000u - sb);   // exactly 1/sz
-            // q = (d > 0 ? -u : u) (:94-98,119).  With lr = 0, in the step loop u > 0 (u = p + half, |p| < half after a
-            // step), so q is u with the sign of nd: one v_bfi.  Only a ray's FIRST step can see u < 0 (origin outside the
-            // region, or the 0.001 face offset across its edge); arm() takes that step itself with the general form.
-            float qx, qy, qz;
-            if (decltype(generic_q)::value || !LRZ) {   // a scrolled region (lr != 0) has u = p + half of either sign
-                qx = r.ndx < 0.0f ? -r.ux : r.ux; qy = r.ndy < 0.0f ? -r.uy : r.uy; qz = r.ndz < 0.0f ? -r.uz : r.uz;
-            } else {
-                qx = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, r.ux) & 0x7FFFFFFFu) | (__builtin_bit_cast(uint32_t, r.ndx) & 0x80000000u));
-                qy = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, r.uy) & 0x7FFFFFFFu) | (__builtin_bit_cast(uint32_t, r.ndy) & 0x80000000u));
-                qz = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, r.uz) & 0x7FFFFFFFu) | (__builtin_bit_cast(uint32_t, r.ndz) & 0x80000000u));
-            }
-            const float mx = __builtin_fmaf(-sz, rtm_floor(qx * is), qx);   // == q - sz*floor(q/sz): both products exact
-            const float my = __builtin_fmaf(-sz, rtm_floor(qy * is), qy);
-            const float mz = __builtin_fmaf(-sz, rtm_floor(qz * is), qz);
-            const float tx = (0.0001f + mx) * r.lx, ty = (0.0001f + my) * r.ly, tz = (0.0001f + mz) * r.lz;
-            const bool xy = tx < ty;
-            const float m1 = xy ? tx : ty;
-            const bool useZ = !(m1 < tz);
-            const float t = useZ ? tz : m1;
-            r.axis = useZ ? 2u : (xy ? 0u : 1u);
-            r.px = __builtin_fmaf(-r.ndx, t, r.px); r.py = __builtin_fmaf(-r.ndy, t, r.py); r.pz = __builtin_fmaf(-r.ndz, t, r.pz);   // fused (rt_math.h contract)
-            r.nk++;
-            r.ux = r.px + half; r.uy = r.py + half; r.uz = r.pz + half;
-            const bool sky = LRZ ? (rtm_abs(r.px) >= half || rtm_abs(r.py) >= half || rtm_abs(r.pz) >= half)
-                                 : (rtm_abs(r.px - f.lr[0]) >= half || rtm_abs(r.py - f.lr[1]) >= half || rtm_abs(r.pz - f.lr[2]) >= half);
-            if (sky) {
-                r.nk |= PX_AIR << 16; r.tracing = false;
-            } else if (LRZ) {
-                const int ix = (int)r.ux & (R - 1), iy = (int)r.uy & (R - 1), iz = (int)r.uz & (R - 1);
-                r.vox = swizzled_index(ix, iy, iz, LB);
-                if (LOGR != 8) r.cidx = coarse_index(ix, iy, iz, LOGR);
-            } else {
-                int ix, iy, iz;
-                r.valid = wrap_texel(v3(r.px, r.py, r.pz), (float)R, &ix, &iy, &iz);
-                if (COUNT && !r.valid) c_border++;
-                r.vox = swizzled_index(ix, iy, iz, LB);
-                if (LOGR != 8) r.cidx = coarse_index(ix, iy, iz, LOGR);
-            }
-        }
-    };
-    auto advance = [&](RaySlot2& r, uint32_t step) { advance_t(r, step, std::false_type{}); };
-    // ---- head of trace_ray (:83-107); needs r.l* set ------------------------------------------------------------------
+    // ---- the ray machinery of rt_dda.hpp bound to this kernel's constants ---------------------------------------------
+    const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
+    auto advance = [&](RaySlot2& r, uint32_t step) { dda_advance<LOGR, LRZ, COUNT, false>(r, step, f, half, c_border); };
     auto arm = [&](RaySlot2& r, float dx, float dy, float dz, float rox, float roy, float roz, bool ok, uint32_t vox0,
-                   uint32_t cidx0) {
-        r.px = rox; r.py = roy; r.pz = roz;
-        r.ndx = -dx; r.ndy = -dy; r.ndz = -dz;
-        r.ux = rox + half; r.uy = roy + half; r.uz = roz + half;
-        r.valid = true; r.fresh_invalid = !ok; r.vox = vox0; r.cidx = cidx0;
-        r.nk = 0; r.axis = 2; r.tracing = true;
-        // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
-        if (dx != dx || dy != dy || dz != dz || !ok) { r.nk = 1u | PX_SPECIAL << 16; r.tracing = false; }
-        if (LRZ && r.tracing && (r.ux < 0.0f || r.uy < 0.0f || r.uz < 0.0f)) {   // rare: see advance_t
-            const uint32_t b = LOGR == 8 ? r.vox >> 6 : r.cidx;
-            uint32_t st = (reinterpret_cast<const uint8_t*>(s_coarse)[b >> 1] >> ((b & 1u) << 2)) & 15u;
-            if (st == kNibMixed) st = sc.mine[r.vox];
-            advance_t(r, st, std::true_type{});
-        }
+                   uint32_t cidx0) {   // needs r.l* set
+        dda_arm<LOGR, LRZ, COUNT>(r, dx, dy, dz, rox, roy, roz, ok, vox0, cidx0, f, half, s_nib, sc, c_border);
     };
-    auto tally = [&](const RaySlot2& r) {   // exact counters of one finished ray
-        const uint32_t kind = r2_kind(r);
-        c_iter += r.nk & 0xFFFFu;
-        if (kind == PX_AIR) {
-            c_sky++;
-            int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
-            if (!wrap_texel(v3(r.px, r.py, r.pz), (float)R, &tx, &ty, &tz)) c_border++;
-        } else if (kind == PX_LIMIT) c_limit++;
-        else c_hits++;
-        if (kind == PX_SPECIAL) c_border += 1u + (r.fresh_invalid ? 1u : 0u);
-        else if (r.fresh_invalid) c_border++;
+    auto tally = [&](const RaySlot2& r) {
+        RayTally t;
+        dda_tally<LOGR>(r, t);
+        c_iter += t.iter; c_hits += t.hits; c_sky += t.sky; c_limit += t.limit; c_border += t.border;
     };
     // the shadow ray of a context ended: note its result (:326-328 / :338-340) and start the level's diffuse ray (:330 / :342)
     auto rearm = [&](Ctx2& c) {
@@ -878,7 +899,6 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
             do {
                 // fetches of both contexts first (:106 for a fresh ray, :137 otherwise), so their latencies overlap
                 const uint32_t bA = LOGR == 8 ? A.r.vox >> 6 : A.r.cidx, bB = LOGR == 8 ? B.r.vox >> 6 : B.r.cidx;
-                const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
                 const uint32_t wA = s_nib[bA >> 1], wB = s_nib[bB >> 1];
                 uint32_t stA = (wA >> ((bA & 1u) << 2)) & 15u, stB = (wB >> ((bB & 1u) << 2)) & 15u;
                 const bool gA = A.r.tracing && stA == kNibMixed, gB = B.r.tracing && stB == kNibMixed;
@@ -985,9 +1005,33 @@ hipError_t launch_dif_lut(const float4* sphere, float4* lut, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count, hipStream_t st) {
+template <int LOGR>
+static void launch_primary2_logr(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count, dim3 grid,
+                                 hipStream_t st) {
+    const dim3 block(1024);
+    if (f.lr_zero != 0) {
+        if (count) hipLaunchKernelGGL((k_primary2<LOGR, true, true>), grid, block, 0, st, sc, f, pl, a);
+        else hipLaunchKernelGGL((k_primary2<LOGR, true, false>), grid, block, 0, st, sc, f, pl, a);
+    } else {
+        if (count) hipLaunchKernelGGL((k_primary2<LOGR, false, true>), grid, block, 0, st, sc, f, pl, a);
+        else hipLaunchKernelGGL((k_primary2<LOGR, false, false>), grid, block, 0, st, sc, f, pl, a);
+    }
+}
+
+hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count, int version,
+                          int nworkgroups, hipStream_t st) {
     const uint32_t npix_pad = (uint32_t)f.ntiles_local * 64u;
     if (npix_pad == 0) return hipSuccess;
+    if (version == 2) {
+        // one workgroup per CU, but no more than there are 16-tile shares of work
+        const int want = (f.ntiles_local + 15) / 16;
+        const dim3 grid(want < nworkgroups ? want : nworkgroups);
+        if (f.logr == 8) launch_primary2_logr<8>(sc, f, pl, a, count, grid, st);
+        else if (f.logr == 9) launch_primary2_logr<9>(sc, f, pl, a, count, grid, st);
+        else if (f.logr == 10) launch_primary2_logr<10>(sc, f, pl, a, count, grid, st);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     dim3 grid((npix_pad + 255u) / 256u), block(256);
     if (count) hipLaunchKernelGGL(k_primary<true>, grid, block, 0, st, sc, f, pl, a);
     else hipLaunchKernelGGL(k_primary<false>, grid, block, 0, st, sc, f, pl, a);

@@ -119,9 +119,12 @@ def test_seed_clamp_and_wrap(procedural_region, blue_noise):
         _compare(gpu, cpu, gcn, ccn)
 
 
+@pytest.mark.parametrize("prepass", ["1", "2"])
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 64, 1, 2), (96, 72, 4, 0), (100, 60, 5, 3), (128, 128, 8, 4)])
-def test_primary_cache_same_pixels(procedural_region, blue_noise, W, H, spp, depth):
-    """RT_FLAG_CACHE_PRIMARY traces the seed-independent primary ray once per pixel: identical planes, fewer rays."""
+def test_primary_cache_same_pixels(procedural_region, blue_noise, W, H, spp, depth, prepass, monkeypatch):
+    """RT_FLAG_CACHE_PRIMARY traces the seed-independent primary ray once per pixel: identical planes, fewer rays.
+    Both prepass kernels: k_primary2 (default: nibble map in LDS) and k_primary (RT_PRIMARY_V=1: one thread per pixel)."""
+    monkeypatch.setenv("RT_PRIMARY_V", prepass)
     mats, mine = procedural_region
     u = _uniforms(seed=3)
     cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
