@@ -116,7 +116,7 @@ def main():
     W, H, SPP, D = args.width, args.height, args.spp, args.depth
     if args.kernel == "default":   # what RT_KERNEL_DEFAULT resolves to for this workload (rt_create); named so the report says which
         tiles = ((args.width + 7) // 8) * ((args.height + 7) // 8)
-        args.kernel = "persistent2" if (tiles + world - 1) // world * 64 * args.spp >= (24 << 20) else "persistent"
+        args.kernel = "persistent2" if (tiles + world - 1) // world * 64 * args.spp >= (12 << 20) else "persistent"
     kernel = {"persistent": abi.RT_KERNEL_PERSISTENT, "persistent2": abi.RT_KERNEL_PERSISTENT2, "wavefront": abi.RT_KERNEL_WAVEFRONT,
               "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0

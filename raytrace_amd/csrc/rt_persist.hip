@@ -432,7 +432,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 if (S.tracing) advance(S, stS);
                 if (F.tracing) advance(F, stF);
             } while ((uint32_t)__popcll(__ballot(S.tracing || F.tracing)) > target);
-            continue;
+            continue;   // (k_persist2 falls through into its pass instead; here the compiler's code is faster this way)
         }
         if (n_wait == 0u) break;   // nothing in flight, nothing parked, no paths left
 
@@ -894,9 +894,9 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
     uint64_t mA = 0, mB = 0, shA = 0, shB = 0, pkA = ~0ull, pkB = ~0ull;
     for (;;) {
         uint64_t needA = ~mA & pkA, needB = ~mB & pkB;
-        if ((uint32_t)__popcll(needA) < threshold && (uint32_t)__popcll(needB) < threshold && (mA | mB) != 0ull) {
-            // ---- step loop ----------------------------------------------------------------------------------------
-            do {
+        {
+            // ---- step loop (falls through into the pass: no detour over the outer loop's header) --------------------
+            while ((uint32_t)__popcll(needA) < threshold && (uint32_t)__popcll(needB) < threshold && (mA | mB) != 0ull) {
                 // fetches of both contexts first (:106 for a fresh ray, :137 otherwise), so their latencies overlap
                 const uint32_t bA = LOGR == 8 ? A.r.vox >> 6 : A.r.cidx, bB = LOGR == 8 ? B.r.vox >> 6 : B.r.cidx;
                 const uint32_t wA = s_nib[bA >> 1], wB = s_nib[bB >> 1];
@@ -922,8 +922,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
                     shA &= ~rA; shB &= ~rB; pkA |= rA; pkB |= rB;
                 }
                 needA = ~mA & pkA; needB = ~mB & pkB;
-            } while ((uint32_t)__popcll(needA) < threshold && (uint32_t)__popcll(needB) < threshold && (mA | mB) != 0ull);
-            continue;
+            }
         }
         if ((needA | needB) == 0ull) {
             // no ray in flight and no context parked: only finished shadow rays can be left
