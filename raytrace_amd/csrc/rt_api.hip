@@ -79,6 +79,8 @@ struct RtContext {
     uint32_t persist_batch = 1;
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
     int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2)
+    float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
+    bool lut_valid = false;
     int primary_version = 2;      // 1 = k_primary (thread per pixel), 2 = k_primary2 (nibble map in LDS); RT_PRIMARY_V
     rtd::DevCounters* d_counters = nullptr;
     uint64_t host_noise_base = 0, host_frames = 0;
@@ -497,10 +499,14 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
             pr.worklist = ctx->worklist; pr.wl_count = ctx->pcursor + 1; pr.acc = ctx->pacc; pr.counters = ctx->d_counters;
             e = rtd::launch_primary(scene_of(ctx), f, planes_of(ctx), pr, count, ctx->primary_version, ctx->num_cus, ctx->stream);
         }
-        if (e == hipSuccess && ctx->cfg.depth >= 1) {
+        // the two per-frame tables depend on the sun vector and colour only: rebuilt when those change (bit compare)
+        float lut_key[6] = {f.sunangle[0], f.sunangle[1], f.sunangle[2], f.sunlight[0], f.sunlight[1], f.sunlight[2]};
+        if (e == hipSuccess && ctx->cfg.depth >= 1 && (!ctx->lut_valid || memcmp(lut_key, ctx->lut_key, sizeof(lut_key)) != 0)) {
             LaunchTimer t(ctx, 1);
             e = rtd::launch_sun_lut(f, ctx->sun_lut, ctx->stream);
             if (e == hipSuccess) e = rtd::launch_sky_lut(f, ctx->dif_lut, ctx->stream);
+            ctx->lut_valid = e == hipSuccess;
+            memcpy(ctx->lut_key, lut_key, sizeof(lut_key));
         }
         if (!cache || ctx->cfg.depth >= 1) {
             const uint32_t spp = (uint32_t)ctx->cfg.spp, B = ctx->persist_batch;

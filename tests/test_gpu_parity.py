@@ -471,3 +471,20 @@ def test_sample_batches_accumulate_in_order(procedural_region, blue_noise, kerne
     for flags in (0, abi.RT_FLAG_CACHE_PRIMARY):
         gpu, _ = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=flags)
         _compare(gpu, cpu)
+
+
+def test_per_frame_tables_follow_the_sun(procedural_region, blue_noise):
+    """The shadow-direction and sky tables are rebuilt only when the sun vector changes: frames with sun 0.0, 0.9, 0.9, 0.0
+    on ONE context must each match the oracle."""
+    mats, mine = procedural_region
+    W, H, spp, depth = 80, 48, 2, 3
+    cfg = render.make_config(W, H, spp=spp, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        for sun in (0.0, 0.9, 0.9, 0.0):
+            u = po.camera_uniforms((-30.0, -128.0, 100.0), np.pi / 2, -0.1, sun, 7)
+            cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+            ctx.draw_frame(u)
+            ctx.sync()
+            _compare(ctx.readback_all(), cpu)
