@@ -488,3 +488,20 @@ def test_per_frame_tables_follow_the_sun(procedural_region, blue_noise):
             ctx.draw_frame(u)
             ctx.sync()
             _compare(ctx.readback_all(), cpu)
+
+
+@pytest.mark.parametrize("threshold,rmin", [(1, 1), (64, 128), (17, 3)])
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2])
+def test_scheduling_parameters_do_not_change_results(procedural_region, blue_noise, kernel, threshold, rmin, monkeypatch):
+    """The parked-lane threshold of the transition pass and the re-arm trigger only regroup the work: planes and counters
+    stay those of the oracle at the extremes too (pass per finished lane / only when the whole wave is parked)."""
+    monkeypatch.setenv("RT_PERSIST_THRESHOLD", str(threshold))
+    monkeypatch.setenv("RT_PERSIST_RMIN", str(rmin))
+    mats, mine = procedural_region
+    u = _uniforms(seed=13)
+    W, H, spp, depth = 88, 56, 3, 4
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel)
+    _compare(gpu, cpu, gcn, ccn)
+    gpu, _ = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=abi.RT_FLAG_CACHE_PRIMARY)
+    _compare(gpu, cpu)
