@@ -102,7 +102,8 @@ typedef enum RtKernel {
 
 #define RT_FLAG_COUNTERS      0x1u  /* count rays/iterations/hits exactly (slower; for B_alg + parity)   */
 #define RT_FLAG_CACHE_PRIMARY 0x2u  /* spp>1: trace the (seed-independent) primary ray once per pixel    */
-#define RT_FLAG_TIMING        0x4u  /* bracket every kernel launch with HIP events (rt_get_timing detail)  */
+#define RT_FLAG_TIMING        0x4u  /* bracket the traversal-kernel launches with HIP events (RtTiming.trace_ms)  */
+#define RT_FLAG_TIMING_ALL    0xCu  /* ... and every other launch as well (RtTiming.shade_ms); includes RT_FLAG_TIMING */
 
 /*
  * RtConfig — replaces the compile-time window constants (constants.rs:9-10) and adds the
@@ -166,8 +167,8 @@ typedef struct RtCounters {
     uint64_t frames;
 } RtCounters;
 
-/* HIP-event timings, milliseconds.  frame_ms = the last rt_draw_frame; the per-launch sums (RT_FLAG_TIMING) cover
- * every frame drawn since the previous rt_get_timing call. */
+/* HIP-event timings, milliseconds.  frame_ms = the last rt_draw_frame; the per-launch sums (RT_FLAG_TIMING: trace_ms,
+ * RT_FLAG_TIMING_ALL: shade_ms too) cover every frame drawn since the previous rt_get_timing call. */
 typedef struct RtTiming {
     float    frame_ms;        /* whole frame on the context's stream                      */
     float    trace_ms;        /* sum of traversal-kernel launches                         */

@@ -23,6 +23,7 @@ RT_KERNEL_DEFAULT, RT_KERNEL_MEGA, RT_KERNEL_WAVEFRONT, RT_KERNEL_PERSISTENT, RT
 RT_FLAG_COUNTERS = 0x1
 RT_FLAG_CACHE_PRIMARY = 0x2
 RT_FLAG_TIMING = 0x4
+RT_FLAG_TIMING_ALL = 0xC
 
 (RT_BUF_LIGHTING_RGBA16, RT_BUF_DEPTH_R16UI, RT_BUF_NORMAL_R8UI, RT_BUF_ALBEDO_RGBA8,
  RT_BUF_EMISSION_RGBA8, RT_BUF_FOG_RGBA8, RT_BUF_LIGHTING_F32, RT_BUF_FOG_F32,

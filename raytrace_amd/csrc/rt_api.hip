@@ -178,7 +178,9 @@ rtd::Frame frame_of(const RtContext* c, const RtUniforms* u) {
 // Event pair bracketing one launch (only with RT_FLAG_TIMING).
 struct LaunchTimer {
     RtContext* c; bool on; size_t idx;
-    LaunchTimer(RtContext* ctx, int kind) : c(ctx), on((ctx->cfg.flags & RT_FLAG_TIMING) != 0), idx(0) {
+    // kind 0 = traversal kernel (RT_FLAG_TIMING), 1 = any other launch (RT_FLAG_TIMING_ALL: each pair of events costs a few us)
+    LaunchTimer(RtContext* ctx, int kind)
+        : c(ctx), on(kind == 0 ? (ctx->cfg.flags & RT_FLAG_TIMING) != 0 : (ctx->cfg.flags & RT_FLAG_TIMING_ALL) == RT_FLAG_TIMING_ALL), idx(0) {
         if (!on) return;
         if (c->ev_used + 2 > c->ev_pool.size()) {
             for (int k = 0; k < 2; k++) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } c->ev_pool.push_back(e); }

@@ -6,7 +6,7 @@ noise = np.fromfile('tests/golden/blue_noise_512.rgba', dtype=np.uint8)
 mats, mine = world.generate_region()
 u = render.camera_uniforms((-30.0,-128.0,100.0), np.pi/2, 0.0, 0.0, 1)
 for (W,H,spp,D) in ((1024,1024,1,2),(1920,1080,64,4)):
-    cfg = render.make_config(W,H,spp=spp,depth=D,flags=abi.RT_FLAG_CACHE_PRIMARY|abi.RT_FLAG_TIMING)
+    cfg = render.make_config(W,H,spp=spp,depth=D,flags=abi.RT_FLAG_CACHE_PRIMARY|abi.RT_FLAG_TIMING_ALL)
     with render.Context(cfg) as ctx:
         ctx.upload_world(mats, mine); ctx.upload_noise(noise)
         for it in range(3):
