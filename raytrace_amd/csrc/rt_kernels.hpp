@@ -46,7 +46,7 @@ struct ShadeArgs {
     DevCounters* counters;
 };
 
-// k_primary (rt_persist.hip): primary prepass.  Arrays are indexed by local pixel.
+// k_primary / k_primary2 (rt_persist.hip): primary prepass.  Arrays are indexed by worklist slot (acc: by local pixel).
 struct PrimaryArgs {
     float *phx, *phy, *phz;     // primary hit position (with the 0.001 face offset) of queued pixels
     uint32_t* pinfo;            // material[20:0] | face id << 24
@@ -58,7 +58,7 @@ struct PrimaryArgs {
 // k_persist (rt_persist.hip): persistent path kernel.  Work item r = sample_in_batch * nwork + w.
 struct PersistArgs {
     uint32_t* cursor;           // next path to hand out (zero before launch)
-    const uint32_t* worklist;   // CACHE: pixels queued by k_primary
+    const uint32_t* worklist;   // CACHE: pixels queued by the prepass
     const uint32_t* wl_count;   // CACHE: number of queued pixels (nwork)
     uint32_t npix_pad;          // CACHE=false: nwork = all local pixels (padded to whole 8x8 tiles)
     uint32_t sample0, nsamples; // samples of this batch: sample0 .. sample0+nsamples-1

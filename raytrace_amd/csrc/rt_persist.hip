@@ -1,22 +1,26 @@
 // rt_persist.hip — the production kernels of the ray-trace path.
 //
-//   k_primary : one thread per pixel (8x8 tile per wave, so the wave's rays are coherent): primary ray, the five
-//               primary-only G-buffer planes, finished lighting for sky pixels, and a __ballot-compacted worklist of
-//               the pixels that still need shadow/diffuse rays together with their primary hits (SoA in HBM).
-//   k_persist : persistent wave64 path kernel.  One 1024-thread workgroup per CU stays resident for the frame and
-//               shares a 128 KiB nibble map of the scene in LDS.  A lane owns one path (pixel, sample) at a time and
-//               keeps its whole state in registers: level, shadow bits, and the level's TWO rays (shadow + diffuse)
-//               which it walks together.  All lanes run the same DDA step loop.  A lane whose rays have ended parks;
-//               when `threshold` lanes of the wave are parked (__ballot) the wave runs ONE transition pass for all of
-//               them — consume the results, shade, start the next level (directions come from tables), or finish
-//               the path and pull the next one from the wave's 512-path chunk of the global cursor (one atomicAdd per
-//               chunk, paths dealt out ballot-ranked) — so shading runs on a well-filled wave and the step loop on
-//               compacted work.  Per path one 16-byte light record goes to HBM; k_accumulate_paths adds a pixel's
-//               samples in order.
+//   k_primary2 : primary prepass.  One 1024-thread workgroup per CU, nibble map of the scene in LDS; a wave walks whole
+//                8x8 tiles (lane = pixel, so the wave's rays are coherent): primary ray, the five primary-only G-buffer
+//                planes, finished lighting for sky pixels, and a __ballot-compacted worklist of the pixels that still
+//                need shadow/diffuse rays together with their primary hits (SoA in HBM).  (k_primary: the same with
+//                one thread per pixel over the byte array, RT_PRIMARY_V=1.)
+//   k_persist  : persistent wave64 path kernel.  One 1024-thread workgroup per CU stays resident for the frame and
+//                shares a 128 KiB nibble map of the scene in LDS.  A lane owns one path (pixel, sample) at a time and
+//                keeps its whole state in registers: level, shadow bits, and the level's TWO rays (shadow + diffuse)
+//                which it walks together.  All lanes run the same DDA step loop.  A lane whose rays have ended parks;
+//                when `threshold` lanes of the wave are parked (__ballot) the wave runs ONE transition pass for all of
+//                them — consume the results, shade, start the next level (directions come from tables), or finish
+//                the path and pull the next one from the wave's 512-path chunk of the global cursor (one atomicAdd per
+//                chunk, paths dealt out ballot-ranked) — so shading runs on a well-filled wave and the step loop on
+//                compacted work.  Per path one 16-byte light record goes to HBM; k_accumulate_paths adds a pixel's
+//                samples in order.
+//   k_persist2 : the same machinery regrouped — a lane carries two paths, each walking its level's shadow ray and then
+//                its diffuse ray in one ray slot (rt_dda.hpp); the kernel RT_KERNEL_DEFAULT picks for large frames.
 //
 // The primary ray does not depend on the seed (raytrace.comp:306-320 reads no noise), so with RT_FLAG_CACHE_PRIMARY
-// it is traced once per pixel (k_primary) and every sample starts at its first shadow ray.  Without the flag
-// k_persist<CACHE=false> walks every pixel itself and re-traces the primary ray for each sample (the reference's
+// it is traced once per pixel (prepass) and every sample starts at its first shadow ray.  Without the flag the path
+// kernels (CACHE=false) walk every pixel themselves and re-trace the primary ray for each sample (the reference's
 // ray count; used for counter parity).
 //
 // Values are those of raytrace.comp; only the grouping of the work differs (see the loop note in rt_kernels.hip).
