@@ -38,8 +38,21 @@ __device__ __forceinline__ uint32_t dda_lookup(const RaySlot2& r, const uint8_t*
 
 // One loop iteration (:109-161) with the fetched value `step` of the current texel.  GENERIC_Q: q for u of either sign
 // (always used when lr != 0; with lr = 0 only a ray's first step can see u < 0 — dda_arm takes that step itself).
+// s_swz (R = 256 with lr = 0 only, else unused): LDS tables [3][kSwzStride] of the swizzled-index contribution of each
+// coordinate value 0..256 (256 = the wrap to texel 0), so the index of the next texel is three table reads OR-ed
+// together instead of 14 shift/mask operations.
+constexpr int kSwzStride = 260;
+template <int LOGR, bool LRZ>
+constexpr bool dda_uses_swz() { return LOGR == 8 && LRZ; }
+__device__ __forceinline__ void dda_fill_swz(uint32_t* s_swz, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < 3u * 257u; i += nthreads) {
+        const uint32_t a = i / 257u, v = (i % 257u) & 255u;
+        s_swz[a * kSwzStride + i % 257u] = ((v & 3u) << (2u * a)) | ((v >> 2) << (6u + 6u * a));
+    }
+}
 template <int LOGR, bool LRZ, bool COUNT, bool GENERIC_Q>
-__device__ __forceinline__ void dda_advance(RaySlot2& r, uint32_t step, const Frame& f, float half, unsigned long long& c_border) {
+__device__ __forceinline__ void dda_advance(RaySlot2& r, uint32_t step, const Frame& f, float half, unsigned long long& c_border,
+                                            const uint32_t* s_swz) {
     constexpr int R = 1 << LOGR, LB = LOGR - 2;
     if (!LRZ && !r.valid) step = 0u;
     if (step == 0u) {
@@ -78,6 +91,8 @@ __device__ __forceinline__ void dda_advance(RaySlot2& r, uint32_t step, const Fr
                              : (rtm_abs(r.px - f.lr[0]) >= half || rtm_abs(r.py - f.lr[1]) >= half || rtm_abs(r.pz - f.lr[2]) >= half);
         if (sky) {
             r.nk |= PX_AIR << 16; r.tracing = false;
+        } else if (dda_uses_swz<LOGR, LRZ>()) {
+            r.vox = s_swz[(int)r.ux] | s_swz[kSwzStride + (int)r.uy] | s_swz[2 * kSwzStride + (int)r.uz];   // u in [0, 256]
         } else if (LRZ) {
             const int ix = (int)r.ux & (R - 1), iy = (int)r.uy & (R - 1), iz = (int)r.uz & (R - 1);
             r.vox = swizzled_index(ix, iy, iz, LB);
@@ -97,7 +112,7 @@ __device__ __forceinline__ void dda_advance(RaySlot2& r, uint32_t step, const Fr
 template <int LOGR, bool LRZ, bool COUNT>
 __device__ __forceinline__ void dda_arm(RaySlot2& r, float dx, float dy, float dz, float rox, float roy, float roz, bool ok,
                                         uint32_t vox0, uint32_t cidx0, const Frame& f, float half, const uint8_t* s_nib,
-                                        const Scene& sc, unsigned long long& c_border) {
+                                        const Scene& sc, unsigned long long& c_border, const uint32_t* s_swz) {
     r.px = rox; r.py = roy; r.pz = roz;
     r.ndx = -dx; r.ndy = -dy; r.ndz = -dz;
     r.ux = rox + half; r.uy = roy + half; r.uz = roz + half;
@@ -106,7 +121,7 @@ __device__ __forceinline__ void dda_arm(RaySlot2& r, float dx, float dy, float d
     // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
     if (dx != dx || dy != dy || dz != dz || !ok) { r.nk = 1u | PX_SPECIAL << 16; r.tracing = false; }
     if (LRZ && r.tracing && (r.ux < 0.0f || r.uy < 0.0f || r.uz < 0.0f))   // rare (origin outside the region): see dda_advance
-        dda_advance<LOGR, LRZ, COUNT, true>(r, dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border);
+        dda_advance<LOGR, LRZ, COUNT, true>(r, dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border, s_swz);
 }
 
 // Exact counters of one finished ray (the counting build's share of SURVEY 8d's integers).

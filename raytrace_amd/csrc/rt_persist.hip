@@ -148,11 +148,13 @@ __global__ __launch_bounds__(256) void k_primary(Scene sc, Frame f, Planes pl, P
 template <int LOGR, bool LRZ, bool COUNT>
 __global__ __launch_bounds__(1024) void k_primary2(Scene sc, Frame f, Planes pl, PrimaryArgs a) {
     __shared__ uint32_t s_coarse[kCoarseWords];
+    __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];
     __shared__ uint32_t s_cnt[16], s_off[17];   // worklist append: pixels queued by each wave this round, their slot offsets
     {
         const uint4* src = reinterpret_cast<const uint4*>(sc.coarse);
         uint4* dst = reinterpret_cast<uint4*>(s_coarse);
         for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
+        if (dda_uses_swz<LOGR, LRZ>()) dda_fill_swz(s_swz, threadIdx.x, 1024u);
     }
     __syncthreads();
     const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
@@ -181,10 +183,10 @@ __global__ __launch_bounds__(1024) void k_primary2(Scene sc, Frame f, Planes pl,
             int ix, iy, iz;
             const bool ok = wrap_texel(start, (float)R, &ix, &iy, &iz);
             dda_arm<LOGR, LRZ, COUNT>(r, d.x, d.y, d.z, start.x, start.y, start.z, ok, swizzled_index(ix, iy, iz, LB),
-                                      coarse_index(ix, iy, iz, LOGR), f, half, s_nib, sc, c_border);
+                                      coarse_index(ix, iy, iz, LOGR), f, half, s_nib, sc, c_border, s_swz);
         }
         while (__ballot(r.tracing)) {
-            if (r.tracing) dda_advance<LOGR, LRZ, COUNT, false>(r, dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border);
+            if (r.tracing) dda_advance<LOGR, LRZ, COUNT, false>(r, dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border, s_swz);
         }
         bool queue = false;
         vec3 qpos = v3(0, 0, 0);
@@ -663,6 +665,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
     __shared__ uint32_t s_coarse[kCoarseWords];
     __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
     __shared__ float s_org[2][3][1024];        // origin of the waiting diffuse ray: [path id][component][thread]
+    __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];   // swizzle tables (rt_dda.hpp)
     const uint32_t nwork = CACHE ? *a.wl_count : a.npix_pad;
     const uint32_t nitems = nwork * a.nsamples;
     if (nitems == 0u) return;
@@ -671,6 +674,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
         uint4* dst = reinterpret_cast<uint4*>(s_coarse);
         for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
         if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
+        if (dda_uses_swz<LOGR, LRZ>()) dda_fill_swz(s_swz, threadIdx.x, 1024u);
     }
     __syncthreads();
 
@@ -705,10 +709,10 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
 
     // ---- the ray machinery of rt_dda.hpp bound to this kernel's constants ---------------------------------------------
     const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
-    auto advance = [&](RaySlot2& r, uint32_t step) { dda_advance<LOGR, LRZ, COUNT, false>(r, step, f, half, c_border); };
+    auto advance = [&](RaySlot2& r, uint32_t step) { dda_advance<LOGR, LRZ, COUNT, false>(r, step, f, half, c_border, s_swz); };
     auto arm = [&](RaySlot2& r, float dx, float dy, float dz, float rox, float roy, float roz, bool ok, uint32_t vox0,
                    uint32_t cidx0) {   // needs r.l* set
-        dda_arm<LOGR, LRZ, COUNT>(r, dx, dy, dz, rox, roy, roz, ok, vox0, cidx0, f, half, s_nib, sc, c_border);
+        dda_arm<LOGR, LRZ, COUNT>(r, dx, dy, dz, rox, roy, roz, ok, vox0, cidx0, f, half, s_nib, sc, c_border, s_swz);
     };
     auto tally = [&](const RaySlot2& r) {
         RayTally t;
