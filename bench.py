@@ -161,6 +161,12 @@ def main():
         c0.destroy()
         trace_bytes_local -= cn0.minefield_fetches + 4 * cn0.material_fetches
 
+    # RCCL gather overlapped with the next frame (RT_BENCH_OVERLAP=0: serial).  The path kernels are persistent and fill
+    # every CU (k_persist2 uses all 128 VGPRs of each SIMD), so a concurrent RCCL kernel needs CUs of its own:
+    # RT_RESERVE_CUS keeps that many out of the path kernels' grids (rt_create reads it).
+    overlap = dist_on and backend == "nccl" and os.environ.get("RT_BENCH_OVERLAP", "1") != "0"
+    if overlap and world > 1:
+        os.environ.setdefault("RT_RESERVE_CUS", "8")
     ctx = make_ctx(abi.RT_FLAG_TIMING)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
@@ -175,10 +181,43 @@ def main():
         local_view = torch.as_tensor(_DevArray(ctx.gbuffer_ptr(), gbytes), device=dev)
         gathered = torch.empty(world * gbytes, dtype=torch.uint8, device=dev) if rank == 0 else None
         frames = {b: torch.empty(W * H * bpp[b], dtype=torch.uint8, device=dev) if rank == 0 else None for b in gather_ids}
+    if overlap:
+        # Pipelined gather (RCCL only): frame k's block is copied to one of two staging tensors and gathered asynchronously
+        # while frame k+1 renders; its scatter into the row-major frame runs one step later.  The fence flushes the pipe.
+        stage = [torch.empty(gbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        gathered2 = [torch.empty(world * gbytes, dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
+        pending = [None, None]
+        pipe = {"frame": 0, "open": None}
+
+    def scatter(block):
+        if rank == 0 and world > 1:
+            ctx.untile_gbuffer(block.data_ptr(), world, [frames[b].data_ptr() for b in gather_ids])
+        elif rank == 0:   # forced single-rank run: the block already holds row-major planes
+            for b in gather_ids:
+                off = ctx.gbuffer_offset(b)
+                frames[b].copy_(block[off:off + frames[b].numel()])
+
+    def finish(slot):
+        pending[slot].wait()          # the current stream waits for that gather (no host block)
+        pending[slot] = None
+        scatter(gathered2[slot])
+
+    def flush():
+        if overlap and pipe["open"] is not None:
+            finish(pipe["open"])
+            pipe["open"] = None
 
     def step():
         ctx.draw_frame(u)
-        if dist_on:
+        if overlap:
+            s = pipe["frame"] & 1
+            stage[s].copy_(local_view)           # after the frame on the current stream; frees the context's block
+            pending[s] = dist.gather(stage[s], list(gathered2[s].chunk(world)) if rank == 0 else None, dst=0, async_op=True)
+            if pipe["open"] is not None:
+                finish(pipe["open"])             # the previous frame: its gather had this frame's render time to complete
+            pipe["open"] = s
+            pipe["frame"] += 1
+        elif dist_on:
             if backend == "nccl":
                 if rank == 0:
                     dist.gather(local_view, list(gathered.chunk(world)), dst=0)
@@ -192,14 +231,10 @@ def main():
                     gathered.copy_(torch.cat(parts))
                 else:
                     dist.gather(host, None, dst=0)
-            if rank == 0 and world > 1:
-                ctx.untile_gbuffer(gathered.data_ptr(), world, [frames[b].data_ptr() for b in gather_ids])
-            elif rank == 0:   # forced single-rank run: the block already holds row-major planes
-                for b in gather_ids:
-                    off = ctx.gbuffer_offset(b)
-                    frames[b].copy_(gathered[off:off + frames[b].numel()])
+            scatter(gathered)
 
     def fence():
+        flush()
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -261,7 +296,8 @@ def main():
             "config": {"workload": "%dx%d spp=%d depth=%d, procedural %d^3 region seed 0x5EED, pose (%g,%g,%g) h=pi/2 p=0 sun=0"
                                    % ((W, H, SPP, D, REGION) + tuple(pose["origin"])), "kernel": args.kernel, "rays_per_frame": int(rays_total), "reference_equivalent_rays_per_frame": int(ref_rays_total),
                        "algorithmic_bytes_per_frame": int(balg_total), "parallelism": "tiles%d" % world,
-                       "primary_cache": bool(args.cache_primary), "frame_sha256_16": frame_sha},
+                       "primary_cache": bool(args.cache_primary), "frame_sha256_16": frame_sha,
+                       "gather": None if not dist_on else ("overlapped with the next frame" if overlap else "serial")},
             "roofline": {"bound": "hbm", "kernel": {"persistent": "k_persist", "persistent2": "k_persist2", "wavefront": "k_trace", "mega": "k_mega"}[args.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launches_per_frame": trace_launches // max(args.steps, 1),

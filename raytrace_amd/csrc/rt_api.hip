@@ -305,6 +305,9 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     hipDeviceProp_t prop;
     RT_HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // RT_RESERVE_CUS=n: the persistent kernels (one workgroup per CU) leave n CUs free, e.g. for an RCCL kernel running
+    // beside them (bench.py's overlapped gather)
+    if (const char* s = getenv("RT_RESERVE_CUS")) { int v = atoi(s); if (v > 0 && v < c->num_cus) c->num_cus -= v; }
     RT_HIP_CREATE(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     RT_HIP_CREATE(hipEventCreate(&c->ev_frame0));

@@ -370,13 +370,16 @@ def test_bench_rccl_path_single_rank():
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    env = dict(os.environ, RT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    env.pop("RT_BENCH_BACKEND", None)
-    forced = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
-    assert forced.returncode == 0, forced.stderr[-3000:]
-    j2 = json.loads([l for l in forced.stdout.splitlines() if l.startswith("{")][-1])
-    assert j1["config"]["frame_sha256_16"] == j2["config"]["frame_sha256_16"]
-    assert j1["config"]["rays_per_frame"] == j2["config"]["rays_per_frame"]
+    for overlap, port in (("1", "29537"), ("0", "29538")):   # pipelined gather (default) and the serial one
+        env = dict(os.environ, RT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                   RT_BENCH_OVERLAP=overlap)
+        env.pop("RT_BENCH_BACKEND", None)
+        forced = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+        assert forced.returncode == 0, forced.stderr[-3000:]
+        j2 = json.loads([l for l in forced.stdout.splitlines() if l.startswith("{")][-1])
+        assert j1["config"]["frame_sha256_16"] == j2["config"]["frame_sha256_16"]
+        assert j1["config"]["rays_per_frame"] == j2["config"]["rays_per_frame"]
+        assert j2["config"]["gather"] == ("overlapped with the next frame" if overlap == "1" else "serial")
 
 
 @pytest.fixture(scope="module")
