@@ -114,11 +114,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     W, H, SPP, D = args.width, args.height, args.spp, args.depth
-    if args.kernel == "default":   # what RT_KERNEL_DEFAULT resolves to for this workload (rt_create); named so the report says which
-        tiles = ((args.width + 7) // 8) * ((args.height + 7) // 8)
-        args.kernel = "persistent2" if (tiles + world - 1) // world * 64 * args.spp >= (12 << 20) else "persistent"
-    kernel = {"persistent": abi.RT_KERNEL_PERSISTENT, "persistent2": abi.RT_KERNEL_PERSISTENT2, "wavefront": abi.RT_KERNEL_WAVEFRONT,
-              "mega": abi.RT_KERNEL_MEGA}[args.kernel]
+    kernel = {"default": abi.RT_KERNEL_DEFAULT, "persistent": abi.RT_KERNEL_PERSISTENT, "persistent2": abi.RT_KERNEL_PERSISTENT2,
+              "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
     noise = np.fromfile(os.path.join(ROOT, "tests", "golden", "blue_noise_512.rgba"), dtype=np.uint8)
     REGION = args.region
@@ -138,6 +135,9 @@ def main():
 
     # ---- exact ray / byte counts of one frame (deterministic; outside the timed region) --------------------
     cctx = make_ctx(abi.RT_FLAG_COUNTERS)
+    # the report names the kernel the library actually runs (RT_KERNEL_DEFAULT picks by workload size, rt_create)
+    args.kernel = {abi.RT_KERNEL_PERSISTENT: "persistent", abi.RT_KERNEL_PERSISTENT2: "persistent2",
+                   abi.RT_KERNEL_WAVEFRONT: "wavefront", abi.RT_KERNEL_MEGA: "mega"}[cctx.kernel_in_use()]
     cctx.draw_frame(u)
     cctx.sync()
     cn = cctx.counters()

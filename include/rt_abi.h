@@ -263,6 +263,9 @@ int rt_denoise_planes(RtContext* ctx, void* lighting_rgba16, const void* depth_r
 int rt_finalize_planes(RtContext* ctx, const void* albedo_rgba8, const void* emission_rgba8, const void* fog_rgba8,
                        const void* lighting_rgba16, const void* depth_r16, void* out_bgra8);
 
+/* The traversal implementation the context runs (what RT_KERNEL_DEFAULT resolved to); negative RtStatus on a null context. */
+int rt_kernel_in_use(RtContext* ctx);
+
 int rt_get_counters(RtContext* ctx, RtCounters* out);
 int rt_reset_counters(RtContext* ctx);
 int rt_get_timing(RtContext* ctx, RtTiming* out);

@@ -14,7 +14,7 @@ ABI_SYMBOLS = (
     "rt_create", "rt_destroy", "rt_last_error", "rt_upload_world", "rt_upload_slice", "rt_upload_noise",
     "rt_draw_frame", "rt_sync", "rt_readback", "rt_buffer_bytes", "rt_device_ptr", "rt_set_stream",
     "rt_tile_count", "rt_tile_capacity", "rt_untile", "rt_gbuffer_ptr", "rt_gbuffer_bytes", "rt_gbuffer_offset",
-    "rt_untile_gbuffer", "rt_denoise", "rt_finalize", "rt_denoise_planes", "rt_finalize_planes", "rt_get_counters", "rt_reset_counters", "rt_get_timing",
+    "rt_untile_gbuffer", "rt_denoise", "rt_finalize", "rt_denoise_planes", "rt_finalize_planes", "rt_kernel_in_use", "rt_get_counters", "rt_reset_counters", "rt_get_timing",
     "rt_abi_version",
 )
 
@@ -68,6 +68,8 @@ def amd():
         lib.rt_finalize.argtypes = [P]
         lib.rt_denoise_planes.argtypes = [P, P, P, P, C.c_int]
         lib.rt_finalize_planes.argtypes = [P, P, P, P, P, P, P]
+        lib.rt_kernel_in_use.argtypes = [P]
+        lib.rt_kernel_in_use.restype = C.c_int
         lib.rt_get_counters.argtypes = [P, C.POINTER(RtCounters)]
         lib.rt_reset_counters.argtypes = [P]
         lib.rt_get_timing.argtypes = [P, C.POINTER(RtTiming)]

@@ -663,6 +663,12 @@ int rt_untile_gbuffer(RtContext* ctx, const void* gathered_dev, int world, void*
     return RT_OK;
 }
 
+int rt_kernel_in_use(RtContext* ctx) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 2) return RT_KERNEL_PERSISTENT2;
+    return ctx->kernel;
+}
+
 int rt_get_counters(RtContext* ctx, RtCounters* out) {
     if (!ctx || !out) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));

@@ -178,6 +178,10 @@ class Context:
                                                  C.c_void_p(lighting_ptr), C.c_void_p(depth_ptr), C.c_void_p(out_ptr)))
 
     # -- instrumentation ---------------------------------------------------------------------------------
+    def kernel_in_use(self):
+        """RtKernel the context runs (what RT_KERNEL_DEFAULT resolved to)."""
+        return int(self._lib.rt_kernel_in_use(self._h))
+
     def counters(self):
         cn = RtCounters()
         self._check(self._lib.rt_get_counters(self._h, C.byref(cn)))
