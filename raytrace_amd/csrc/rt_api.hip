@@ -531,15 +531,12 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 }
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 1);
-                    e = rtd::launch_accumulate_paths(ctx->ppl, ctx->worklist, ctx->pcursor + 1, ctx->npix_pad, ns,
-                                                     s0 == 0, cache, ctx->pacc, ctx->stream);
+                    e = rtd::launch_accumulate_paths(f, planes_of(ctx), ctx->ppl, ctx->worklist, ctx->pcursor + 1, ctx->npix_pad, ns,
+                                                     s0 == 0, s0 + B >= spp, cache, ctx->pacc, ctx->stream);
                 }
             }
         }
-        if (e == hipSuccess) {
-            LaunchTimer t(ctx, 1);
-            e = rtd::launch_resolve(f, ctx->pacc, planes_of(ctx), ctx->npix_pad, ctx->stream);
-        }
+        // (no resolve launch: the prepass and the last accumulate of the frame store the lighting planes themselves)
         if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("persistent path: ") + hipGetErrorString(e));
     } else {
         rc = draw_wavefront(ctx, f);

@@ -52,7 +52,7 @@ struct PrimaryArgs {
     uint32_t* pinfo;            // material[20:0] | face id << 24
     uint32_t* worklist;         // local pixel ids that need shadow/diffuse rays
     uint32_t* wl_count;         // zero before launch
-    float4* acc;                // per-pixel light sum of finished (sky / depth 0) pixels
+    float4* acc;                // (unused by the prepass since it stores the lighting of the pixels it finishes itself)
     DevCounters* counters;
 };
 // k_persist (rt_persist.hip): persistent path kernel.  Work item r = sample_in_batch * nwork + w.
@@ -73,9 +73,9 @@ struct PersistArgs {
     float4* pl;                 // [nsamples * nwork] light of each path (one 16-byte store per path)
     DevCounters* counters;
 };
-hipError_t launch_accumulate_paths(const float4* pl, const uint32_t* worklist,
-                                   const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool cache,
-                                   float4* acc, hipStream_t st);
+hipError_t launch_accumulate_paths(const Frame& f, const Planes& planes, const float4* pl, const uint32_t* worklist,
+                                   const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool last_batch,
+                                   bool cache, float4* acc, hipStream_t st);
 hipError_t launch_sphere_lut(float4* lut, hipStream_t st);
 hipError_t launch_dif_lut(const float4* sphere, float4* lut, hipStream_t st);
 hipError_t launch_sun_lut(const Frame& f, float4* lut, hipStream_t st);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_primary(Scene sc, Frame f, Planes pl, P
             if (h.air) light = sample_sky(dir, ld3(f.sunangle), ld3(f.sunlight), true);            // raytrace.comp:321-322
             vec3 sum = v3(0.0f, 0.0f, 0.0f);
             for (int s = 0; s < f.spp; s++) sum = vadd(sum, light);
-            a.acc[lp] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+            store_lighting(pl, pix.out_index, sum, f.spp);
         } else {
             queue = true;
             qpos = h.position; qnormal = h.normal;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(1024) void k_primary2(Scene sc, Frame f, Planes pl,
                 if (air) light = sample_sky(dir, ld3(f.sunangle), ld3(f.sunlight), true);            // raytrace.comp:321-322
                 vec3 sum = v3(0.0f, 0.0f, 0.0f);
                 for (int s = 0; s < f.spp; s++) sum = vadd(sum, light);
-                a.acc[lp] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+                store_lighting(pl, pix.out_index, sum, f.spp);
             } else {
                 queue = true;
                 qpos = v3(hx, hy, hz); qnormal = nrm;
@@ -965,11 +965,14 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
 }
 
 // acc[pixel] (+)= the batch's samples of that pixel, in sample order (deterministic fp32 sum; raytrace.comp has one
-// sample per frame, the sum over frames is the build's spp extension).
+// sample per frame, the sum over frames is the build's spp extension).  The last batch of a frame writes the pixel's
+// lighting planes itself (sum / spp / 16, raytrace.comp:352-356) — the prepass has done that for the pixels it finished —
+// so no separate resolve launch is needed.
 template <bool CACHE>
-__global__ __launch_bounds__(256) void k_accumulate_paths(const float4* __restrict__ pl, const uint32_t* __restrict__ worklist,
+__global__ __launch_bounds__(256) void k_accumulate_paths(Frame f, Planes planes, const float4* __restrict__ pl,
+                                                          const uint32_t* __restrict__ worklist,
                                                           const uint32_t* __restrict__ wl_count, uint32_t npix_pad,
-                                                          uint32_t nsamples, int first_batch, float4* __restrict__ acc) {
+                                                          uint32_t nsamples, int first_batch, int last_batch, float4* __restrict__ acc) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     const uint32_t nwork = CACHE ? *wl_count : npix_pad;
     if (w >= nwork) return;
@@ -979,16 +982,21 @@ __global__ __launch_bounds__(256) void k_accumulate_paths(const float4* __restri
         const float4 l = pl[(size_t)b * nwork + w];
         v.x = v.x + l.x; v.y = v.y + l.y; v.z = v.z + l.z;
     }
-    acc[lp] = v;
+    if (last_batch) {
+        const PixelId pix = pixel_of_local(f, lp);
+        if (pix.inside) store_lighting(planes, pix.out_index, v3(v.x, v.y, v.z), f.spp);
+    } else {
+        acc[lp] = v;
+    }
 }
 
-hipError_t launch_accumulate_paths(const float4* pl, const uint32_t* worklist,
-                                   const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool cache,
-                                   float4* acc, hipStream_t st) {
+hipError_t launch_accumulate_paths(const Frame& f, const Planes& planes, const float4* pl, const uint32_t* worklist,
+                                   const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool last_batch,
+                                   bool cache, float4* acc, hipStream_t st) {
     if (npix_pad == 0) return hipSuccess;
     dim3 grid((npix_pad + 255u) / 256u), block(256);
-    if (cache) hipLaunchKernelGGL(k_accumulate_paths<true>, grid, block, 0, st, pl, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, acc);
-    else hipLaunchKernelGGL(k_accumulate_paths<false>, grid, block, 0, st, pl, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, acc);
+    if (cache) hipLaunchKernelGGL(k_accumulate_paths<true>, grid, block, 0, st, f, planes, pl, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, last_batch ? 1 : 0, acc);
+    else hipLaunchKernelGGL(k_accumulate_paths<false>, grid, block, 0, st, f, planes, pl, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, last_batch ? 1 : 0, acc);
     return hipGetLastError();
 }
 
