@@ -136,8 +136,9 @@ def test_primary_cache_same_pixels(procedural_region, blue_noise, W, H, spp, dep
     assert gcn.rays == ccn.rays - (spp - 1) * W * H
 
 
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2])
 @pytest.mark.parametrize("W,H", [(96, 64), (100, 60)])
-def test_tile_split_contexts_reassemble_to_the_full_frame(procedural_region, blue_noise, W, H):
+def test_tile_split_contexts_reassemble_to_the_full_frame(procedural_region, blue_noise, W, H, kernel):
     """Multi-GPU layout on one GPU: two contexts render the even / odd 8x8 tiles (tile_world = 2), their tile-major
     planes are concatenated rank-major on the device (what the RCCL gather produces) and rt_untile scatters them;
     the result must equal the single-context frame (and hence the oracle) on every plane."""
@@ -149,7 +150,8 @@ def test_tile_split_contexts_reassemble_to_the_full_frame(procedural_region, blu
     world_n = 2
     ctxs = []
     for r in range(world_n):
-        cfg = render.make_config(W, H, spp=spp, depth=depth, tile_rank=r, tile_world=world_n, flags=abi.RT_FLAG_CACHE_PRIMARY)
+        cfg = render.make_config(W, H, spp=spp, depth=depth, tile_rank=r, tile_world=world_n, kernel=kernel,
+                                 flags=abi.RT_FLAG_CACHE_PRIMARY)
         c = render.Context(cfg)
         c.upload_world(mats, mine)
         c.upload_noise(blue_noise)
