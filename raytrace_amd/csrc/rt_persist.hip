@@ -68,18 +68,6 @@ __global__ __launch_bounds__(256) void k_build_dif_lut(const float4* __restrict_
     lut[4 * i + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-__device__ __forceinline__ vec3 diffuse_direction_lut(const float4* __restrict__ lut, uint32_t normal, uint32_t nvtex) {
-    const float4 p = lut[nvtex & 0xFFFFu];
-    vec3 d = v3(p.x, p.y, p.z);
-    if (normal == 0) d.x += 1.0f;
-    else if (normal == 1) d.x -= 1.0f;
-    else if (normal == 2) d.y += 1.0f;
-    else if (normal == 3) d.y -= 1.0f;
-    else if (normal == 4) d.z += 1.0f;
-    else if (normal == 5) d.z -= 1.0f;
-    return vnormalize(d);
-}
-
 // =====================================================================================================
 // k_primary
 // =====================================================================================================
@@ -269,11 +257,7 @@ __global__ __launch_bounds__(256) void k_build_sun_lut(Frame f, float4* __restri
 // CACHE=false, the primary ray).  The two rays of a level are independent (raytrace.comp:325 and :330 both start from
 // the same surface), so stepping them together doubles the memory-level parallelism of the dependent fetch chain and
 // halves the number of transition passes.
-struct RaySlot {
-    float px, py, pz, dx, dy, dz, lx, ly, lz, ux, uy, uz;
-    uint32_t sgnx, sgny, sgnz, vox, cidx, n, axis, kind;   // vox: swizzled voxel index; cidx: nibble-map entry (R > 256 only)
-    bool tracing, valid, fresh, fresh_invalid;
-};
+// (The slot itself is RaySlot2 of rt_dda.hpp.)
 
 // sample_sky(diffuse_direction, ..., true) (raytrace.comp:331-332 / :343-345) for every entry of the diffuse table, written
 // once per frame into the entry's fourth slot: a path that ends on a sky exit reads its sky light instead of
@@ -289,6 +273,7 @@ template <int LOGR, bool LRZ, bool COUNT, bool CACHE>
 __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes pl, PersistArgs a) {
     __shared__ uint32_t s_coarse[kCoarseWords];
     __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
+    __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];   // swizzle tables (rt_dda.hpp)
     // work items: path r = sample_in_batch * nwork + w, w = worklist slot (CACHE) or local pixel (CACHE=false)
     const uint32_t nwork = CACHE ? *a.wl_count : a.npix_pad;
     const uint32_t nitems = nwork * a.nsamples;
@@ -298,6 +283,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
         uint4* dst = reinterpret_cast<uint4*>(s_coarse);
         for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
         if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
+        if (dda_uses_swz<LOGR, LRZ>()) dda_fill_swz(s_swz, threadIdx.x, 1024u);
     }
     __syncthreads();
 
@@ -309,10 +295,10 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     const vec3 sunangle = ld3(f.sunangle), sunlight = ld3(f.sunlight);
     const uint32_t D = (uint32_t)f.depth;
 
-    RaySlot S, F;
-    S.px = S.py = S.pz = S.dx = S.dy = S.lx = S.ly = S.lz = S.ux = S.uy = S.uz = 0.0f; S.dz = 1.0f;
-    S.sgnx = S.sgny = S.sgnz = S.vox = S.cidx = S.n = 0u; S.axis = 2u; S.kind = PX_HIT;
-    S.tracing = false; S.valid = true; S.fresh = false; S.fresh_invalid = false;
+    RaySlot2 S, F;
+    S.px = S.py = S.pz = S.ndx = S.ndy = S.lx = S.ly = S.lz = S.ux = S.uy = S.uz = 0.0f; S.ndz = -1.0f;
+    S.vox = S.cidx = 0u; S.nk = PX_HIT << 16; S.axis = 2u;
+    S.tracing = false; S.valid = true; S.fresh_invalid = false;
     F = S;
     // ---- path state ----
     uint32_t phase = PH_EMPTY;                // PH_EMPTY, PH_PRIMARY (F only, CACHE=false), PH_DIF (= a level: S and F)
@@ -329,83 +315,23 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                        c_noise = 0, c_pix = 0;
     unsigned long long d_iters = 0, d_sx = 0, d_fx = 0, d_sl = 0, d_fl = 0, d_pass = 0, d_pl = 0, d_sky = 0;   // wave-uniform
 
-    // ---- head of trace_ray (:83-107) ---------------------------------------------------------------------------
-    // origin part, shared by the two rays of a level (same surface point): texel of the first fetch (:106, Q6)
-    auto arm = [&](RaySlot& r, vec3 ro, bool ok, uint32_t vox0, uint32_t cidx0) {   // needs r.d*, r.l* set
-        r.px = ro.x; r.py = ro.y; r.pz = ro.z;
-        r.sgnx = r.dx > 0.0f ? 0x80000000u : 0u; r.sgny = r.dy > 0.0f ? 0x80000000u : 0u;           // :94-98
-        r.sgnz = r.dz > 0.0f ? 0x80000000u : 0u;
-        r.ux = ro.x + half; r.uy = ro.y + half; r.uz = ro.z + half;
-        r.valid = ok; r.fresh_invalid = !ok; r.vox = vox0; r.cidx = cidx0;
-        r.n = 0; r.axis = 2; r.fresh = true; r.kind = PX_HIT;
-        if (r.dx != r.dx || r.dy != r.dy || r.dz != r.dz) { r.kind = PX_SPECIAL; r.n = 1; r.tracing = false; }   // NaN direction
-        else r.tracing = true;
+    // ---- the ray machinery of rt_dda.hpp bound to this kernel's constants ---------------------------------------------
+    const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
+    // head of trace_ray (:83-107) from origin ro (shared by the two rays of a level: same surface point); the slot's direction
+    // registers (nd*, l*) are already set
+    auto arm = [&](RaySlot2& r, vec3 ro, bool ok, uint32_t vox0, uint32_t cidx0) {
+        dda_arm<LOGR, LRZ, COUNT>(r, -r.ndx, -r.ndy, -r.ndz, ro.x, ro.y, ro.z, ok, vox0, cidx0, f, half, s_nib, sc, c_border, s_swz);
     };
-    auto set_dir = [&](RaySlot& r, vec3 rd) {
-        vec3 d = vnormalize(rd);                                                                     // :83
-        r.dx = d.x; r.dy = d.y; r.dz = d.z;
+    auto set_dir = [&](RaySlot2& r, vec3 rd) {
+        const vec3 d = vnormalize(rd);                                                               // :83
+        r.ndx = -d.x; r.ndy = -d.y; r.ndz = -d.z;
         r.lx = 1.0f / rtm_abs(d.x); r.ly = 1.0f / rtm_abs(d.y); r.lz = 1.0f / rtm_abs(d.z);           // :88
     };
-
-    // ---- one DDA step: fetch value `step` already looked up -------------------------------------------------------
-    auto advance = [&](RaySlot& r, uint32_t step) {
-        if (!r.valid) step = 0u;
-        if (step == 0u) {
-            r.kind = r.fresh ? PX_SPECIAL : PX_HIT;   // a fresh ray on a 0 has step_size 0 => mod(x,0) = NaN (defined outcome)
-            if (r.fresh) r.n = 1;
-            r.tracing = false;
-        } else if (r.n == (uint32_t)RT_TRACE_LIMIT) {
-            r.kind = PX_LIMIT; r.tracing = false;                                                   // :109 (Q8)
-        } else {
-            r.fresh = false;
-            // advance (:119-136)
-            const uint32_t sb = (step << 23) + (126u << 23);          // float((1 << step) / 2)
-            const float sz = __builtin_bit_cast(float, sb);
-            const float is = __builtin_bit_cast(float, 0x7F000000u - sb);   // exactly 1/sz
-            const float qx = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r.ux) ^ r.sgnx);
-            const float qy = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r.uy) ^ r.sgny);
-            const float qz = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r.uz) ^ r.sgnz);
-            const float mx = __builtin_fmaf(-sz, rtm_floor(qx * is), qx);   // == q - sz*floor(q/sz): both products exact
-            const float my = __builtin_fmaf(-sz, rtm_floor(qy * is), qy);
-            const float mz = __builtin_fmaf(-sz, rtm_floor(qz * is), qz);
-            const float tx = (0.0001f + mx) * r.lx, ty = (0.0001f + my) * r.ly, tz = (0.0001f + mz) * r.lz;
-            const bool xy = tx < ty;
-            const float m1 = xy ? tx : ty;
-            const bool useZ = !(m1 < tz);
-            const float t = useZ ? tz : m1;
-            r.axis = useZ ? 2u : (xy ? 0u : 1u);
-            r.px = __builtin_fmaf(r.dx, t, r.px); r.py = __builtin_fmaf(r.dy, t, r.py); r.pz = __builtin_fmaf(r.dz, t, r.pz);   // fused (rt_math.h contract)
-            r.n++;
-            r.ux = r.px + half; r.uy = r.py + half; r.uz = r.pz + half;
-            // sky test (:138-145), then the address of the next fetch
-            // with lr = 0 the subtraction p - lr is the identity
-            const bool sky = LRZ ? (rtm_abs(r.px) >= half || rtm_abs(r.py) >= half || rtm_abs(r.pz) >= half)
-                                 : (rtm_abs(r.px - f.lr[0]) >= half || rtm_abs(r.py - f.lr[1]) >= half || rtm_abs(r.pz - f.lr[2]) >= half);
-            if (sky) {
-                r.kind = PX_AIR; r.tracing = false;
-            } else if (LRZ) {
-                const int ix = (int)r.ux & (R - 1), iy = (int)r.uy & (R - 1), iz = (int)r.uz & (R - 1);
-                r.vox = swizzled_index(ix, iy, iz, LB);
-                if (LOGR != 8) r.cidx = coarse_index(ix, iy, iz, LOGR);
-            } else {
-                int ix, iy, iz;
-                r.valid = wrap_texel(v3(r.px, r.py, r.pz), (float)R, &ix, &iy, &iz);
-                if (COUNT && !r.valid) c_border++;
-                r.vox = swizzled_index(ix, iy, iz, LB);
-                if (LOGR != 8) r.cidx = coarse_index(ix, iy, iz, LOGR);
-            }
-        }
-    };
-    auto tally = [&](const RaySlot& r) {   // exact counters of one finished ray
-        c_iter += r.n;
-        if (r.kind == PX_AIR) {
-            c_sky++;
-            int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
-            if (!wrap_texel(v3(r.px, r.py, r.pz), (float)R, &tx, &ty, &tz)) c_border++;
-        } else if (r.kind == PX_LIMIT) c_limit++;
-        else c_hits++;
-        if (r.kind == PX_SPECIAL) c_border += 1u + (r.fresh_invalid ? 1u : 0u);
-        else if (r.fresh_invalid) c_border++;
+    auto advance = [&](RaySlot2& r, uint32_t step) { dda_advance<LOGR, LRZ, COUNT, false>(r, step, f, half, c_border, s_swz); };
+    auto tally = [&](const RaySlot2& r) {   // exact counters of one finished ray
+        RayTally t;
+        dda_tally<LOGR>(r, t);
+        c_iter += t.iter; c_hits += t.hits; c_sky += t.sky; c_limit += t.limit; c_border += t.border;
     };
 
     for (;;) {
@@ -422,7 +348,6 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 // nibble-map entry: at R = 256 a coarse cube IS the 4^3 brick, so the entry index is vox >> 6
                 const uint32_t bS = LOGR == 8 ? S.vox >> 6 : S.cidx, bF = LOGR == 8 ? F.vox >> 6 : F.cidx;
                 // byte reads: entry b is nibble (b & 1) of byte b >> 1 (little-endian words, k_build_coarse)
-                const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
                 const uint32_t wS = s_nib[bS >> 1], wF = s_nib[bF >> 1];
                 uint32_t stS = (wS >> ((bS & 1u) << 2)) & 15u, stF = (wF >> ((bF & 1u) << 2)) & 15u;
                 const bool gS = S.tracing && stS == kNibMixed, gF = F.tracing && stF == kNibMixed;
@@ -444,7 +369,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
 
         // =========================== transition pass ===========================================================
         const bool mine = !(S.tracing || F.tracing) && phase != PH_EMPTY;
-        if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); d_sky += (uint32_t)__popcll(__ballot(mine && phase == PH_DIF && F.kind == PX_AIR)); }
+        if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); d_sky += (uint32_t)__popcll(__ballot(mine && phase == PH_DIF && r2_kind(F) == PX_AIR)); }
         bool path_done = false, begin_level = false, need_primary = false;
         vec3 light = v3(0, 0, 0);
         float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
@@ -453,12 +378,13 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             // Diffuse / primary result.  The hit texel is the texel of the last fetch (same position, same wrap:
             // mod((p+128)/256,1)*256 and mod(p+128,256) agree bit for bit), so the material is mat[vox] (:150-154); the
             // position gets the 0.001 face offset (:166-180).
-            const bool air = F.kind == PX_AIR;
-            const uint32_t nrm = F.axis == 0 ? (F.dx > 0.0f ? 1u : 0u) : (F.axis == 1 ? (F.dy > 0.0f ? 3u : 2u) : (F.dz > 0.0f ? 5u : 4u));
+            const uint32_t fkind = r2_kind(F);
+            const bool air = fkind == PX_AIR;
+            const uint32_t nrm = F.axis == 0 ? (F.ndx < 0.0f ? 1u : 0u) : (F.axis == 1 ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
             uint32_t material = 0;
-            if (F.kind == PX_HIT && F.valid) material = sc.mat[F.vox];
+            if (fkind == PX_HIT && (LRZ || F.valid)) material = sc.mat[F.vox];
             float hx = F.px, hy = F.py, hz = F.pz;
-            if (F.kind == PX_SPECIAL) { hx = hy = hz = __builtin_nanf(""); }
+            if (fkind == PX_SPECIAL) { hx = hy = hz = __builtin_nanf(""); }
             const float off = 0.001f;
             if (nrm == 0) hx += off; else if (nrm == 1) hx -= off;
             else if (nrm == 2) hy += off; else if (nrm == 3) hy -= off;
@@ -484,7 +410,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             } else {
                 // a level ended: shadow result (:326-328 / :338-340), then the diffuse result
                 if (COUNT) tally(S);
-                if (S.kind == PX_AIR) sunbits |= 1u << (level - 1);
+                if (r2_kind(S) == PX_AIR) sunbits |= 1u << (level - 1);
                 if (air || level == D) {
                     vec3 sky = v3(0, 0, 0);
                     if (air) { const float4 t = a.dif_lut[dif_entry + 3u]; sky = v3(t.x, t.y, t.z); }   // :331-332 / :343-345, tabulated
@@ -582,14 +508,14 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             const uint32_t se = nvtex & 0xFFFFu;
             if (se != sun_entry) {
                 const float4 sd = a.sun_lut[2u * se], sl = a.sun_lut[2u * se + 1u];
-                S.dx = sd.x; S.dy = sd.y; S.dz = sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
+                S.ndx = -sd.x; S.ndy = -sd.y; S.ndz = -sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
                 sun_entry = se;
             }
             arm(S, ro, ok, vox0, cidx0);
             const uint32_t di = 4u * ((snormal << 16) | se);
             if (di != dif_entry) {
                 const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
-                F.dx = d2.x; F.dy = d2.y; F.dz = d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
+                F.ndx = -d2.x; F.ndy = -d2.y; F.ndz = -d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
                 dif_entry = di;
             }
             arm(F, ro, ok, vox0, cidx0);
