@@ -363,9 +363,10 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 if (S.tracing) advance(S, stS);
                 if (F.tracing) advance(F, stF);
             } while ((uint32_t)__popcll(__ballot(S.tracing || F.tracing)) > target);
-            continue;   // (k_persist2 falls through into its pass instead; here the compiler's code is faster this way)
+            // falls through into the pass
+        } else if (n_wait == 0u) {
+            break;   // nothing in flight, nothing parked, no paths left
         }
-        if (n_wait == 0u) break;   // nothing in flight, nothing parked, no paths left
 
         // =========================== transition pass ===========================================================
         const bool mine = !(S.tracing || F.tracing) && phase != PH_EMPTY;
