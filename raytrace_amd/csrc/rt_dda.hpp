@@ -120,7 +120,7 @@ __device__ __forceinline__ void dda_arm(RaySlot2& r, float dx, float dy, float d
     r.nk = 0; r.axis = 2; r.tracing = true;
     // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
     if (dx != dx || dy != dy || dz != dz || !ok) { r.nk = 1u | PX_SPECIAL << 16; r.tracing = false; }
-    if (LRZ && r.tracing && (r.ux < 0.0f || r.uy < 0.0f || r.uz < 0.0f))   // rare (origin outside the region): see dda_advance
+    if (LRZ && __builtin_expect(r.tracing && (r.ux < 0.0f || r.uy < 0.0f || r.uz < 0.0f), 0))   // rare (origin outside the region): see dda_advance
         dda_advance<LOGR, LRZ, COUNT, true>(r, dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border, s_swz);
 }
 
