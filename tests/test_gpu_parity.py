@@ -510,3 +510,17 @@ def test_scheduling_parameters_do_not_change_results(procedural_region, blue_noi
     _compare(gpu, cpu, gcn, ccn)
     gpu, _ = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=abi.RT_FLAG_CACHE_PRIMARY)
     _compare(gpu, cpu)
+
+
+def test_headline_frame_equals_the_oracle(procedural_region, blue_noise):
+    """bench.py's workload in full — 1920x1080, spp 64, depth 4, default pose — against the oracle on every pixel of every
+    plane, for both path kernels; counters (349 M rays) for the kernel RT_KERNEL_DEFAULT picks at this size."""
+    mats, mine = procedural_region
+    W, H, spp, depth = 1920, 1080, 64, 4
+    u = render.camera_uniforms((-30.0, -128.0, 100.0), np.pi / 2, 0.0, 0.0, seed=1)
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    for kernel in (abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2):
+        gpu, _ = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=abi.RT_FLAG_CACHE_PRIMARY)
+        _compare(gpu, cpu)
+    gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, abi.RT_KERNEL_DEFAULT)
+    _compare(gpu, cpu, gcn, ccn)
