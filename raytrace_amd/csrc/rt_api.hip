@@ -77,6 +77,7 @@ struct RtContext {
     float4* pacc = nullptr;
     float4* ppl = nullptr;
     uint32_t persist_batch = 1;
+    uint32_t persist_chunk = 0;   // RT_PERSIST_CHUNK: paths per cursor atomic (multiple of 64); 0 = automatic
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
     int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2)
     float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
@@ -355,6 +356,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PRIMARY_V")) { int v = atoi(s); if (v == 1 || v == 2) c->primary_version = v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
+    if (const char* s = getenv("RT_PERSIST_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= 4096) c->persist_chunk = (uint32_t)v & ~63u; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
     if (c->persist_threshold == 0) c->persist_threshold = c->persist_version == 2 ? 40u : 32u;   // measured optima
     if (c->kernel == RT_KERNEL_PERSISTENT) {
@@ -520,7 +522,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 if (s0 != 0) e = hipMemsetAsync(ctx->pcursor, 0, sizeof(uint32_t), ctx->stream);
                 rtd::PersistArgs pa{};
                 pa.cursor = ctx->pcursor; pa.worklist = ctx->worklist; pa.wl_count = ctx->pcursor + 1;
-                pa.npix_pad = ctx->npix_pad; pa.sample0 = s0; pa.nsamples = ns; pa.threshold = ctx->persist_threshold; pa.rmin = ctx->persist_rmin;
+                pa.npix_pad = ctx->npix_pad; pa.sample0 = s0; pa.nsamples = ns; pa.threshold = ctx->persist_threshold; pa.rmin = ctx->persist_rmin; pa.chunk = ctx->persist_chunk;
                 pa.nthreads = (uint32_t)ctx->num_cus * 1024u; pa.stack = ctx->pstack;
                 pa.phx = ctx->phx; pa.phy = ctx->phy; pa.phz = ctx->phz; pa.pinfo = ctx->pinfo;
                 pa.sun_lut = ctx->sun_lut; pa.dif_lut = ctx->dif_lut;

@@ -307,11 +307,14 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     uint32_t sun_entry = 0xFFFFFFFFu;         // shadow-table entry held by S's direction registers
     uint32_t nvtex = 0;                       // noise_value texel of the path (raytrace.comp:324,336)
     bool exhausted = false;
-    // paths per cursor atomic: 512 keeps the single counter word far from its ~90 atomics/us limit on big frames; a small
-    // frame takes smaller chunks so that every wave of the grid gets about four (at 512 a 1-spp 1080p frame fed only 57 % of
-    // the waves; eight smaller chunks per wave measured worse again — the atomic rate)
-    uint32_t kChunk = nitems / (gridDim.x * 16u * 4u) & ~63u;
-    kChunk = kChunk < 64u ? 64u : (kChunk > 512u ? 512u : kChunk);
+    // paths per cursor atomic (RT_PERSIST_CHUNK overrides): about four chunks per wave, 128..256.  Measured: 64 saturates the
+    // single counter word (~90 returning atomics/us: 0.30 instead of 0.27 ms on a 1-spp 1080p frame), 512 feeds only 57 % of
+    // the waves on that frame and lengthens the tail of the spp-64 frame (6.75 instead of 6.65 ms)
+    uint32_t kChunk = a.chunk;
+    if (kChunk == 0u) {
+        kChunk = nitems / (gridDim.x * 16u * 4u) & ~63u;
+        kChunk = kChunk < 128u ? 128u : (kChunk > 256u ? 256u : kChunk);
+    }
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of the path range
     uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot) of path chunk_next
 
@@ -630,11 +633,14 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
         B = A; B.st |= 1u << 7;
     }
     bool exhausted = false;
-    // paths per cursor atomic: 512 keeps the single counter word far from its ~90 atomics/us limit on big frames; a small
-    // frame takes smaller chunks so that every wave of the grid gets about four (at 512 a 1-spp 1080p frame fed only 57 % of
-    // the waves; eight smaller chunks per wave measured worse again — the atomic rate)
-    uint32_t kChunk = nitems / (gridDim.x * 16u * 4u) & ~63u;
-    kChunk = kChunk < 64u ? 64u : (kChunk > 512u ? 512u : kChunk);
+    // paths per cursor atomic (RT_PERSIST_CHUNK overrides): about four chunks per wave, 128..256.  Measured: 64 saturates the
+    // single counter word (~90 returning atomics/us: 0.30 instead of 0.27 ms on a 1-spp 1080p frame), 512 feeds only 57 % of
+    // the waves on that frame and lengthens the tail of the spp-64 frame (6.75 instead of 6.65 ms)
+    uint32_t kChunk = a.chunk;
+    if (kChunk == 0u) {
+        kChunk = nitems / (gridDim.x * 16u * 4u) & ~63u;
+        kChunk = kChunk < 128u ? 128u : (kChunk > 256u ? 256u : kChunk);
+    }
     uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of the path range
     uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot) of path chunk_next
 
