@@ -295,11 +295,11 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     c->vox = (size_t)cfg->region * cfg->region * cfg->region;
     {
         // RT_KERNEL_DEFAULT: the two-paths-per-lane kernel wins once a launch has paths to keep both contexts of every lane
-        // busy (measured crossover at 1920x1080: spp 16, i.e. ~32 M pixel-samples per context); below that the
+        // busy (measured crossover at 1920x1080: spp 24, i.e. ~48 M pixel-samples per context); below that the
         // one-path kernel has the shorter ramp-up and tail
         const uint64_t tiles = ((uint64_t)(cfg->width + 7) / 8) * ((uint64_t)(cfg->height + 7) / 8);
         const uint64_t samples = (tiles + cfg->tile_world - 1) / cfg->tile_world * 64u * (uint64_t)cfg->spp;
-        c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? (samples >= (32ull << 20) ? RT_KERNEL_PERSISTENT2 : RT_KERNEL_PERSISTENT) : cfg->kernel;
+        c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? (samples >= (48ull << 20) ? RT_KERNEL_PERSISTENT2 : RT_KERNEL_PERSISTENT) : cfg->kernel;
         if (c->kernel == RT_KERNEL_PERSISTENT2) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 2; }   // same pipeline, other path kernel
     }
     RT_HIP_CREATE(hipSetDevice(c->device));
