@@ -24,6 +24,8 @@ const size_t kBytesPerPixel[RT_BUF_COUNT] = {8, 2, 1, 4, 4, 4, 16, 16, 4, 4};
 
 }  // namespace
 
+constexpr size_t kCursorWords = 8 * 32;   // path cursors of the persistent kernels: one word per XCD group, each on its own 128-byte line
+
 struct RtContext {
     RtConfig cfg{};
     int device = 0;
@@ -66,7 +68,7 @@ struct RtContext {
     float4* acc = nullptr;
     uint32_t* ctrl = nullptr;     // per batch: [RT_MAX_DEPTH+2] pair counts, then [RT_MAX_DEPTH+2] cursors
     // persistent kernel state
-    uint32_t* pcursor = nullptr;   // [0] work cursor, [1] worklist count
+    uint32_t* pcursor = nullptr;   // [0, kCursorWords) path cursors (one per XCD group), [kCursorWords] worklist count
     uint32_t* pstack = nullptr;
     uint32_t* worklist = nullptr;
     float *phx = nullptr, *phy = nullptr, *phz = nullptr;
@@ -294,12 +296,9 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     c->logr = cfg->region == 256 ? 8 : (cfg->region == 512 ? 9 : 10);
     c->vox = (size_t)cfg->region * cfg->region * cfg->region;
     {
-        // RT_KERNEL_DEFAULT: the two-paths-per-lane kernel wins once a launch has paths to keep both contexts of every lane
-        // busy (measured crossover at 1920x1080: spp 24, i.e. ~48 M pixel-samples per context); below that the
-        // one-path kernel has the shorter ramp-up and tail
-        const uint64_t tiles = ((uint64_t)(cfg->width + 7) / 8) * ((uint64_t)(cfg->height + 7) / 8);
-        const uint64_t samples = (tiles + cfg->tile_world - 1) / cfg->tile_world * 64u * (uint64_t)cfg->spp;
-        c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? (samples >= (48ull << 20) ? RT_KERNEL_PERSISTENT2 : RT_KERNEL_PERSISTENT) : cfg->kernel;
+        // RT_KERNEL_DEFAULT = the one-path-per-lane kernel: since the per-XCD cursors it is as fast as the two-path kernel on
+        // the biggest frames (1080p spp 64: 6.36 vs 6.38 ms, 4K spp 256 depth 8: 145 vs 152 ms) and faster on small ones
+        c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PERSISTENT : cfg->kernel;
         if (c->kernel == RT_KERNEL_PERSISTENT2) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 2; }   // same pipeline, other path kernel
     }
     RT_HIP_CREATE(hipSetDevice(c->device));
@@ -360,7 +359,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
     if (c->persist_threshold == 0) c->persist_threshold = c->persist_version == 2 ? 40u : 32u;   // measured optima
     if (c->kernel == RT_KERNEL_PERSISTENT) {
-        RT_HIP_CREATE(dev_alloc(c, &c->pcursor, 2));
+        RT_HIP_CREATE(dev_alloc(c, &c->pcursor, kCursorWords + 1));   // 8 cursor lines + the worklist count
         RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)2 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));
         RT_HIP_CREATE(dev_alloc(c, &c->worklist, (size_t)c->npix_pad));
         RT_HIP_CREATE(dev_alloc(c, &c->phx, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->phy, (size_t)c->npix_pad));
@@ -498,12 +497,12 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("launch_mega: ") + hipGetErrorString(e));
     } else if (ctx->kernel == RT_KERNEL_PERSISTENT) {
         const bool cache = (ctx->cfg.flags & RT_FLAG_CACHE_PRIMARY) != 0;
-        hipError_t e = hipMemsetAsync(ctx->pcursor, 0, 2 * sizeof(uint32_t), ctx->stream);
+        hipError_t e = hipMemsetAsync(ctx->pcursor, 0, (kCursorWords + 1) * sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess && cache) {
             LaunchTimer t(ctx, 1);
             rtd::PrimaryArgs pr{};
             pr.phx = ctx->phx; pr.phy = ctx->phy; pr.phz = ctx->phz; pr.pinfo = ctx->pinfo;
-            pr.worklist = ctx->worklist; pr.wl_count = ctx->pcursor + 1; pr.acc = ctx->pacc; pr.counters = ctx->d_counters;
+            pr.worklist = ctx->worklist; pr.wl_count = ctx->pcursor + kCursorWords; pr.acc = ctx->pacc; pr.counters = ctx->d_counters;
             e = rtd::launch_primary(scene_of(ctx), f, planes_of(ctx), pr, count, ctx->primary_version, ctx->num_cus, ctx->stream);
         }
         // the two per-frame tables depend on the sun vector and colour only: rebuilt when those change (bit compare)
@@ -519,9 +518,9 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
             const uint32_t spp = (uint32_t)ctx->cfg.spp, B = ctx->persist_batch;
             for (uint32_t s0 = 0; s0 < spp && e == hipSuccess; s0 += B) {
                 const uint32_t ns = spp - s0 < B ? spp - s0 : B;
-                if (s0 != 0) e = hipMemsetAsync(ctx->pcursor, 0, sizeof(uint32_t), ctx->stream);
+                if (s0 != 0) e = hipMemsetAsync(ctx->pcursor, 0, kCursorWords * sizeof(uint32_t), ctx->stream);
                 rtd::PersistArgs pa{};
-                pa.cursor = ctx->pcursor; pa.worklist = ctx->worklist; pa.wl_count = ctx->pcursor + 1;
+                pa.cursor = ctx->pcursor; pa.worklist = ctx->worklist; pa.wl_count = ctx->pcursor + kCursorWords;
                 pa.npix_pad = ctx->npix_pad; pa.sample0 = s0; pa.nsamples = ns; pa.threshold = ctx->persist_threshold; pa.rmin = ctx->persist_rmin; pa.chunk = ctx->persist_chunk;
                 pa.nthreads = (uint32_t)ctx->num_cus * 1024u; pa.stack = ctx->pstack;
                 pa.phx = ctx->phx; pa.phy = ctx->phy; pa.phz = ctx->phz; pa.pinfo = ctx->pinfo;
@@ -533,7 +532,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 }
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 1);
-                    e = rtd::launch_accumulate_paths(f, planes_of(ctx), ctx->ppl, ctx->worklist, ctx->pcursor + 1, ctx->npix_pad, ns,
+                    e = rtd::launch_accumulate_paths(f, planes_of(ctx), ctx->ppl, ctx->worklist, ctx->pcursor + kCursorWords, ctx->npix_pad, ns,
                                                      s0 == 0, s0 + B >= spp, cache, ctx->pacc, ctx->stream);
                 }
             }

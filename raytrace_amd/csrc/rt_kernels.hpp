@@ -57,14 +57,14 @@ struct PrimaryArgs {
 };
 // k_persist (rt_persist.hip): persistent path kernel.  Work item r = sample_in_batch * nwork + w.
 struct PersistArgs {
-    uint32_t* cursor;           // next path to hand out (zero before launch)
+    uint32_t* cursor;           // [8][32] next path of each XCD group's share, one word per 128-byte line (zero before launch)
     const uint32_t* worklist;   // CACHE: pixels queued by the prepass
     const uint32_t* wl_count;   // CACHE: number of queued pixels (nwork)
     uint32_t npix_pad;          // CACHE=false: nwork = all local pixels (padded to whole 8x8 tiles)
     uint32_t sample0, nsamples; // samples of this batch: sample0 .. sample0+nsamples-1
     uint32_t threshold;         // parked lanes per wave that trigger a transition pass (1..64)
     uint32_t rmin;              // k_persist2: contexts waiting for their diffuse ray that trigger the in-loop re-arm block
-    uint32_t chunk;             // paths per cursor atomic; 0 = by frame size (about four chunks per wave, 128..256)
+    uint32_t chunk;             // paths per cursor atomic; 0 = the default (128)
     uint32_t nthreads;          // grid size in threads (stride of the albedo stack)
     uint32_t* stack;            // [2][(depth-1)][nthreads] packed material of surface j+1 (only touched when depth >= 2; k_persist uses half)
     const float *phx, *phy, *phz;   // CACHE: primary hit per local pixel

@@ -307,16 +307,14 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     uint32_t sun_entry = 0xFFFFFFFFu;         // shadow-table entry held by S's direction registers
     uint32_t nvtex = 0;                       // noise_value texel of the path (raytrace.comp:324,336)
     bool exhausted = false;
-    // paths per cursor atomic (RT_PERSIST_CHUNK overrides): about four chunks per wave, 128..256.  Measured: 64 saturates the
-    // single counter word (~90 returning atomics/us: 0.30 instead of 0.27 ms on a 1-spp 1080p frame), 512 feeds only 57 % of
-    // the waves on that frame and lengthens the tail of the spp-64 frame (6.75 instead of 6.65 ms)
-    uint32_t kChunk = a.chunk;
-    if (kChunk == 0u) {
-        kChunk = nitems / (gridDim.x * 16u * 4u) & ~63u;
-        kChunk = kChunk < 128u ? 128u : (kChunk > 256u ? 256u : kChunk);
-    }
-    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of the path range
-    uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot) of path chunk_next
+    // paths per cursor atomic (RT_PERSIST_CHUNK overrides).  Measured with the eight per-XCD cursors: 128 is best or equal from
+    // a 1-sample 1024^2 frame to the spp-64 headline frame; 64 costs 2-3 % there (atomic rate), 256 lengthens small frames' tails
+    const uint32_t kChunk = a.chunk ? a.chunk : 128u;
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of an XCD group's share of the paths
+    uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot within the share) of path chunk_next
+    uint32_t chunk_w0 = 0, chunk_nw = 1;      // the share's slot range
+    const uint32_t home_grp = blockIdx.x & 7u;   // workgroups b and b + 8 share an XCD (round-robin dispatch; speed only)
+    uint32_t grp_tries = 0;                   // shares found empty so far, starting with the own group's
 
     unsigned long long c_prim = 0, c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0,
                        c_noise = 0, c_pix = 0;
@@ -454,23 +452,35 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
             const uint32_t nwant = (uint32_t)__popcll(want);
             if (nwant) {
                 if (chunk_next >= chunk_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(a.cursor, kChunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    chunk_next = base;
-                    chunk_end = base + kChunk < nitems ? base + kChunk : nitems;
-                    if (base >= nitems) { exhausted = true; chunk_next = chunk_end = nitems; }
-                    chunk_sb = chunk_next / nwork; chunk_w = chunk_next - chunk_sb * nwork;   // once per chunk
+                    // next chunk: from the share of this workgroup's XCD group first (worklist slots [w0, w0 + nw) of every
+                    // sample: one band of the image, so an XCD's L2 keeps seeing the same part of the scene), then from the
+                    // other groups' shares; eight cursor words also lift the ~90 atomics/us limit of a single one
+                    for (;;) {
+                        if (grp_tries == 8u) { exhausted = true; chunk_next = chunk_end = 0u; break; }
+                        const uint32_t g = (home_grp + grp_tries) & 7u;
+                        const uint32_t w0 = (uint32_t)((uint64_t)nwork * g >> 3), nw = (uint32_t)((uint64_t)nwork * (g + 1u) >> 3) - w0;
+                        const uint32_t ng = nw * a.nsamples;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(a.cursor + 32u * g, kChunk);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base < ng) {
+                            chunk_next = base; chunk_end = base + kChunk < ng ? base + kChunk : ng;
+                            chunk_w0 = w0; chunk_nw = nw;
+                            chunk_sb = base / nw; chunk_w = base - chunk_sb * nw;   // once per chunk
+                            break;
+                        }
+                        grp_tries++;   // that group's share is handed out for good (its cursor only grows)
+                    }
                 }
                 const uint32_t take = min(nwant, chunk_end - chunk_next);
-                const uint32_t first = chunk_next;
                 chunk_next += take;
                 if (phase == PH_EMPTY) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
                     if (rank < take) {
                         // (sample-in-batch, slot) of path first+rank, stepped from the chunk's running position (no division)
                         uint32_t sb = chunk_sb, w = chunk_w + rank;
-                        while (w >= nwork) { w -= nwork; sb++; }
+                        while (w >= chunk_nw) { w -= chunk_nw; sb++; }
+                        w += chunk_w0;   // worklist slot (CACHE) / local pixel
                         uint32_t wgx8 = 0, wgy8 = 0;
                         bool ok = true;
                         if (CACHE) {
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                             wgy8 = owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE;
                         }
                         if (ok) {
-                            item = first + rank; lp = w; samp = a.sample0 + sb;
+                            item = sb * nwork + w; lp = w; samp = a.sample0 + sb;
                             // noise_offset of this path (:298-304) and its noise_value texel (:324, :336).  The bytes are
                             // exact integers in float (texture().r * 255.0 == the byte) and the per-level offset
                             // (level-1) * 2/512 never reaches the next texel, so one integer lookup serves every level
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                     }
                 }
                 chunk_w += take;
-                while (chunk_w >= nwork) { chunk_w -= nwork; chunk_sb++; }
+                while (chunk_w >= chunk_nw) { chunk_w -= chunk_nw; chunk_sb++; }
             }
         }
         // both rays of a level (:324-330 / :336-342): noise_value, shadow ray and diffuse ray from the tables
@@ -633,16 +643,14 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
         B = A; B.st |= 1u << 7;
     }
     bool exhausted = false;
-    // paths per cursor atomic (RT_PERSIST_CHUNK overrides): about four chunks per wave, 128..256.  Measured: 64 saturates the
-    // single counter word (~90 returning atomics/us: 0.30 instead of 0.27 ms on a 1-spp 1080p frame), 512 feeds only 57 % of
-    // the waves on that frame and lengthens the tail of the spp-64 frame (6.75 instead of 6.65 ms)
-    uint32_t kChunk = a.chunk;
-    if (kChunk == 0u) {
-        kChunk = nitems / (gridDim.x * 16u * 4u) & ~63u;
-        kChunk = kChunk < 128u ? 128u : (kChunk > 256u ? 256u : kChunk);
-    }
-    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of the path range
-    uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot) of path chunk_next
+    // paths per cursor atomic (RT_PERSIST_CHUNK overrides).  Measured with the eight per-XCD cursors: 128 is best or equal from
+    // a 1-sample 1024^2 frame to the spp-64 headline frame; 64 costs 2-3 % there (atomic rate), 256 lengthens small frames' tails
+    const uint32_t kChunk = a.chunk ? a.chunk : 128u;
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of an XCD group's share of the paths
+    uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot within the share) of path chunk_next
+    uint32_t chunk_w0 = 0, chunk_nw = 1;      // the share's slot range
+    const uint32_t home_grp = blockIdx.x & 7u;   // workgroups b and b + 8 share an XCD (round-robin dispatch; speed only)
+    uint32_t grp_tries = 0;                   // shares found empty so far, starting with the own group's
 
     unsigned long long c_prim = 0, c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0,
                        c_noise = 0, c_pix = 0;
@@ -757,22 +765,34 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
             const uint32_t nwant = (uint32_t)__popcll(want);
             if (nwant) {
                 if (chunk_next >= chunk_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(a.cursor, kChunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    chunk_next = base;
-                    chunk_end = base + kChunk < nitems ? base + kChunk : nitems;
-                    if (base >= nitems) { exhausted = true; chunk_next = chunk_end = nitems; }
-                    chunk_sb = chunk_next / nwork; chunk_w = chunk_next - chunk_sb * nwork;   // once per chunk
+                    // next chunk: from the share of this workgroup's XCD group first (worklist slots [w0, w0 + nw) of every
+                    // sample: one band of the image, so an XCD's L2 keeps seeing the same part of the scene), then from the
+                    // other groups' shares; eight cursor words also lift the ~90 atomics/us limit of a single one
+                    for (;;) {
+                        if (grp_tries == 8u) { exhausted = true; chunk_next = chunk_end = 0u; break; }
+                        const uint32_t g = (home_grp + grp_tries) & 7u;
+                        const uint32_t w0 = (uint32_t)((uint64_t)nwork * g >> 3), nw = (uint32_t)((uint64_t)nwork * (g + 1u) >> 3) - w0;
+                        const uint32_t ng = nw * a.nsamples;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(a.cursor + 32u * g, kChunk);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base < ng) {
+                            chunk_next = base; chunk_end = base + kChunk < ng ? base + kChunk : ng;
+                            chunk_w0 = w0; chunk_nw = nw;
+                            chunk_sb = base / nw; chunk_w = base - chunk_sb * nw;   // once per chunk
+                            break;
+                        }
+                        grp_tries++;   // that group's share is handed out for good (its cursor only grows)
+                    }
                 }
                 const uint32_t take = min(nwant, chunk_end - chunk_next);
-                const uint32_t first = chunk_next;
                 chunk_next += take;
                 if (wantme) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
                     if (rank < take) {
                         uint32_t sb = chunk_sb, w = chunk_w + rank;
-                        while (w >= nwork) { w -= nwork; sb++; }
+                        while (w >= chunk_nw) { w -= chunk_nw; sb++; }
+                        w += chunk_w0;   // worklist slot (CACHE) / local pixel
                         uint32_t wgx8 = 0, wgy8 = 0;
                         bool ok = true;
                         if (CACHE) {
@@ -787,7 +807,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
                         }
                         if (ok) {
                             C.st = (C.st & 0x80u) | 7u << 8 | P2_EMPTY;   // face id 7: q* hold no table entry of this path
-                            C.item = first + rank; C.lp = w; C.samp = a.sample0 + sb;
+                            C.item = sb * nwork + w; C.lp = w; C.samp = a.sample0 + sb;
                             const uint32_t seed = (f.seed + C.samp) % (uint32_t)RT_NOISE_BYTES;
                             const uint32_t by = seed / RT_NOISE_SIZE;
                             const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
@@ -799,7 +819,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
                     }
                 }
                 chunk_w += take;
-                while (chunk_w >= nwork) { chunk_w -= nwork; chunk_sb++; }
+                while (chunk_w >= chunk_nw) { chunk_w -= chunk_nw; chunk_sb++; }
             }
         }
         // both rays of a level (:324-330 / :336-342): the shadow ray starts now; the diffuse ray's table entry, first texel
