@@ -162,7 +162,7 @@ def main():
         trace_bytes_local -= cn0.minefield_fetches + 4 * cn0.material_fetches
 
     # RCCL gather overlapped with the next frame (RT_BENCH_OVERLAP=0: serial).  The path kernels are persistent and fill
-    # every CU (k_persist2 uses all 128 VGPRs of each SIMD), so a concurrent RCCL kernel needs CUs of its own:
+    # every CU with a 1024-thread workgroup holding 130+ KiB of LDS, so a concurrent RCCL kernel is given CUs of its own:
     # RT_RESERVE_CUS keeps that many out of the path kernels' grids (rt_create reads it).
     overlap = dist_on and backend == "nccl" and os.environ.get("RT_BENCH_OVERLAP", "1") != "0"
     if overlap and world > 1:
