@@ -274,6 +274,10 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     __shared__ uint32_t s_coarse[kCoarseWords];
     __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
     __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];   // swizzle tables (rt_dda.hpp)
+    // albedo stack of the lane's path (packed material of surface j+1 at level j) for depths up to kLdsStack + 1: the LDS the
+    // nibble map leaves holds exactly seven levels for 1024 threads; deeper frames use the global stack
+    constexpr uint32_t kLdsStack = 7;
+    __shared__ uint32_t s_stack[kLdsStack][1024];
     // work items: path r = sample_in_batch * nwork + w, w = worklist slot (CACHE) or local pixel (CACHE=false)
     const uint32_t nwork = CACHE ? *a.wl_count : a.npix_pad;
     const uint32_t nitems = nwork * a.nsamples;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                     if (sunbits >> (level - 1) & 1u) L = vadd(L, sunlight);
                     if (air) L = vadd(L, sky);
                     for (uint32_t j = level - 1; j >= 1u; j--) {
-                        const uint32_t pm = a.stack[(size_t)(j - 1) * a.nthreads + gtid];
+                        const uint32_t pm = D - 1u <= kLdsStack ? s_stack[j - 1][threadIdx.x] : a.stack[(size_t)(j - 1) * a.nthreads + gtid];
                         vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
                         light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
                         vec3 acc = v3(0.0f, 0.0f, 0.0f);
@@ -435,7 +439,8 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                     light = vadd(v3(0.0f, 0.0f, 0.0f), L);
                     path_done = true;
                 } else {
-                    a.stack[(size_t)(level - 1) * a.nthreads + gtid] = material;   // albedo of surface level+1
+                    if (D - 1u <= kLdsStack) s_stack[level - 1][threadIdx.x] = material;   // albedo of surface level+1
+                    else a.stack[(size_t)(level - 1) * a.nthreads + gtid] = material;
                     sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
                     level++; begin_level = true;
                 }
