@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4)
-    ap.add_argument("--kernel", choices=["default", "persistent", "persistent2", "wavefront", "mega"], default="default")
+    ap.add_argument("--kernel", choices=["default", "paths", "persistent", "persistent2", "wavefront", "mega"], default="default")
     ap.add_argument("--no-cache-primary", dest="cache_primary", action="store_false",
                     help="re-trace the (seed-independent) primary ray for every sample, like spp reference frames would")
     ap.set_defaults(cache_primary=True)
@@ -114,7 +114,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     W, H, SPP, D = args.width, args.height, args.spp, args.depth
-    kernel = {"default": abi.RT_KERNEL_DEFAULT, "persistent": abi.RT_KERNEL_PERSISTENT, "persistent2": abi.RT_KERNEL_PERSISTENT2,
+    kernel = {"default": abi.RT_KERNEL_DEFAULT, "paths": abi.RT_KERNEL_PATHS, "persistent": abi.RT_KERNEL_PERSISTENT, "persistent2": abi.RT_KERNEL_PERSISTENT2,
               "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
     noise = np.fromfile(os.path.join(ROOT, "tests", "golden", "blue_noise_512.rgba"), dtype=np.uint8)
@@ -136,7 +136,7 @@ def main():
     # ---- exact ray / byte counts of one frame (deterministic; outside the timed region) --------------------
     cctx = make_ctx(abi.RT_FLAG_COUNTERS)
     # the report names the kernel the library actually runs (RT_KERNEL_DEFAULT picks by workload size, rt_create)
-    args.kernel = {abi.RT_KERNEL_PERSISTENT: "persistent", abi.RT_KERNEL_PERSISTENT2: "persistent2",
+    args.kernel = {abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent", abi.RT_KERNEL_PERSISTENT2: "persistent2",
                    abi.RT_KERNEL_WAVEFRONT: "wavefront", abi.RT_KERNEL_MEGA: "mega"}[cctx.kernel_in_use()]
     cctx.draw_frame(u)
     cctx.sync()
@@ -147,7 +147,7 @@ def main():
     trace_bytes_local = cn.minefield_fetches + 4 * cn.material_fetches
     balg_local = cn.algorithmic_bytes()
     ref_equiv_rays_local = cn.rays + (SPP - 1) * cn.pixels if args.cache_primary else cn.rays
-    if args.kernel in ("persistent", "persistent2") and args.cache_primary and D >= 1:
+    if args.kernel in ("paths", "persistent", "persistent2") and args.cache_primary and D >= 1:
         # the dominant kernel (k_persist) walks only shadow/diffuse rays; the primary prepass (k_primary) is a separate,
         # untimed-for-roofline launch: subtract its share, measured with a depth-0 counting frame
         cfg0 = render.make_config(W, H, spp=SPP, depth=0, device=local_rank, tile_rank=rank, tile_world=world,
@@ -285,7 +285,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_r1.json")
         if os.path.exists(tpath) and (W, H, SPP, D, REGION) == (1920, 1080, 64, 4, 256) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get("k_%s_hbm_bytes_per_launch" % {"persistent": "persist", "persistent2": "persist2", "wavefront": "trace", "mega": "mega"}[args.kernel])
+                traffic = json.load(open(tpath)).get("k_%s_hbm_bytes_per_launch" % {"paths": "paths", "persistent": "persist", "persistent2": "persist2", "wavefront": "trace", "mega": "mega"}[args.kernel])
             except Exception:
                 traffic = None
         out = {
@@ -298,7 +298,7 @@ def main():
                        "algorithmic_bytes_per_frame": int(balg_total), "parallelism": "tiles%d" % world,
                        "primary_cache": bool(args.cache_primary), "frame_sha256_16": frame_sha,
                        "gather": None if not dist_on else ("overlapped with the next frame" if overlap else "serial")},
-            "roofline": {"bound": "hbm", "kernel": {"persistent": "k_persist", "persistent2": "k_persist2", "wavefront": "k_trace", "mega": "k_mega"}[args.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": {"paths": "k_paths", "persistent": "k_persist", "persistent2": "k_persist2", "wavefront": "k_trace", "mega": "k_mega"}[args.kernel], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launches_per_frame": trace_launches // max(args.steps, 1),
                          "avg_launch_ms": round(trace_ms / max(trace_launches, 1), 4),

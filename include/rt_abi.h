@@ -91,14 +91,17 @@ typedef struct RtUniforms {
 
 /* Which traversal implementation a context uses. */
 typedef enum RtKernel {
-    RT_KERNEL_DEFAULT = 0,    /* library picks (persistent)                                                    */
+    RT_KERNEL_DEFAULT = 0,    /* library picks (paths)                                                         */
     RT_KERNEL_MEGA = 1,       /* one thread per pixel, all rays inline, byte minefield from HBM (baseline)      */
     RT_KERNEL_WAVEFRONT = 2,  /* split stages: persistent traversal kernel fed by SoA ray/hit queues in HBM     */
     RT_KERNEL_PERSISTENT = 3, /* production kernel: persistent wave64 path kernel, a lane owns a path with its shadow
                                  and diffuse ray in two ray slots, state in registers, __ballot batched transitions,
                                  nibble map in LDS, per-XCD path cursors                                         */
-    RT_KERNEL_PERSISTENT2 = 4 /* same machinery, but a lane carries TWO paths, each walking its shadow ray then its
+    RT_KERNEL_PERSISTENT2 = 4,/* same machinery, but a lane carries TWO paths, each walking its shadow ray then its
                                  diffuse ray in one slot (fuller waves, heavier transitions)        */
+    RT_KERNEL_PATHS = 5       /* a lane carries two paths with two ray slots each (four fetch chains in flight per lane) and
+                                 the step loop is branch-free; frames it does not cover (lr != 0, no primary cache,
+                                 region != 256) run on RT_KERNEL_PERSISTENT                                      */
 } RtKernel;
 
 #define RT_FLAG_COUNTERS      0x1u  /* count rays/iterations/hits exactly (slower; for B_alg + parity)   */

@@ -81,7 +81,7 @@ struct RtContext {
     uint32_t persist_batch = 1;
     uint32_t persist_chunk = 0;   // RT_PERSIST_CHUNK: paths per cursor atomic (multiple of 64); 0 = automatic
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
-    int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2)
+    int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2), 3 = k_paths (RT_KERNEL_PATHS)
     float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
     bool lut_valid = false;
     int primary_version = 2;      // 1 = k_primary (thread per pixel), 2 = k_primary2 (nibble map in LDS); RT_PRIMARY_V
@@ -274,7 +274,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (cfg->depth < 0 || cfg->depth > RT_MAX_DEPTH) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: depth out of range");
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: bad tile_rank/tile_world");
-    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_PERSISTENT2)
+    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_PATHS)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown kernel");
 
     int ndev = 0;
@@ -296,10 +296,11 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     c->logr = cfg->region == 256 ? 8 : (cfg->region == 512 ? 9 : 10);
     c->vox = (size_t)cfg->region * cfg->region * cfg->region;
     {
-        // RT_KERNEL_DEFAULT = the one-path-per-lane kernel: since the per-XCD cursors it is as fast as the two-path kernel on
-        // the biggest frames (1080p spp 64: 6.36 vs 6.38 ms, 4K spp 256 depth 8: 145 vs 152 ms) and faster on small ones
-        c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PERSISTENT : cfg->kernel;
+        // RT_KERNEL_DEFAULT = k_paths (two paths, four ray slots per lane, branch-free step loop); the frames it does not
+        // cover run on k_persist (rt_draw_frame decides per frame: lr is a per-frame uniform)
+        c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PATHS : cfg->kernel;
         if (c->kernel == RT_KERNEL_PERSISTENT2) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 2; }   // same pipeline, other path kernel
+        if (c->kernel == RT_KERNEL_PATHS) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 3; }
     }
     RT_HIP_CREATE(hipSetDevice(c->device));
     hipDeviceProp_t prop;
@@ -528,7 +529,10 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 pa.pl = ctx->ppl; pa.counters = ctx->d_counters;
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 0);
-                    e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->persist_version, ctx->num_cus, ctx->stream);
+                    if (ctx->persist_version == 3 && cache && f.lr_zero != 0 && f.logr == 8)
+                        e = rtd::launch_paths(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->num_cus, ctx->stream);
+                    else
+                        e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->persist_version == 2 ? 2 : 1, ctx->num_cus, ctx->stream);
                 }
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 1);
@@ -664,6 +668,7 @@ int rt_untile_gbuffer(RtContext* ctx, const void* gathered_dev, int world, void*
 int rt_kernel_in_use(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 2) return RT_KERNEL_PERSISTENT2;
+    if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 3) return RT_KERNEL_PATHS;
     return ctx->kernel;
 }
 
@@ -682,7 +687,9 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
         fprintf(stderr, "[rt] wave loop iters %llu | S block execs %llu (avg lanes %.1f) | F block execs %llu (avg lanes %.1f) | passes %llu "
                         "(avg lanes %.1f, sky lanes %.1f)\n", d.dbg_loop_iters, d.dbg_s_execs, d.dbg_s_execs ? (double)d.dbg_s_lanes / d.dbg_s_execs : 0.0,
                 d.dbg_f_execs, d.dbg_f_execs ? (double)d.dbg_f_lanes / d.dbg_f_execs : 0.0, d.dbg_passes,
-                d.dbg_passes ? (double)d.dbg_pass_lanes / d.dbg_passes : 0.0, d.dbg_passes ? (double)d.dbg_sky_lanes / d.dbg_passes : 0.0);
+                d.dbg_passes ? (double)d.dbg_pass_lanes / d.dbg_passes : 0.0, d.dbg_passes ? (double)d.dbg_sky_lanes / d.dbg_passes : 0.0),
+        fprintf(stderr, "[rt] raw: loop_iters %llu s_lanes %llu f_lanes %llu passes %llu pass_lanes %llu\n", d.dbg_loop_iters, d.dbg_s_lanes,
+                d.dbg_f_lanes, d.dbg_passes, d.dbg_pass_lanes);
     return RT_OK;
 }
 

@@ -86,6 +86,10 @@ hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, con
 hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
                           int version /* 1 = k_persist, 2 = k_persist2 */, int nworkgroups, hipStream_t st);
 
+// k_paths (rt_paths.hip): cached-primary frames with lr = 0 and region 256 only
+hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nworkgroups,
+                        hipStream_t st);
+
 hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
                           uint32_t* coarse, uint32_t* bad_flag, int logr, hipStream_t st);
 hipError_t launch_mega(const Scene& sc, const Frame& f, const Planes& pl, DevCounters* cn, bool count, hipStream_t st);

@@ -1,0 +1,402 @@
+// rt_paths.hip — k_paths, the path kernel RT_KERNEL_DEFAULT runs for cached-primary frames with lr = 0.
+//
+// Same work, same values as k_persist (rt_persist.hip); what differs is how much of it a wave keeps in flight and how the
+// step loop is issued:
+//   * a lane carries TWO paths (contexts A and B), each with the level's shadow ray and diffuse ray in their own ray slots:
+//     four independent fetch chains per lane instead of two.  k_persist ran at an LDS-pinned four waves per SIMD with 75 of
+//     its 128 VGPRs and its waves parked at s_waitcnt half of their life (round-1 counters); the idle registers now hold
+//     the second path.
+//   * the step loop is ONE basic block: every slot's step is predicated with selects instead of exec-mask branches and the
+//     byte behind a "mixed" nibble-map entry is a buffer load whose offset is out of range for lanes that do not need it
+//     (no memory access, returns 0).  The compiler can therefore issue the four nibble reads, then the four byte loads, and
+//     overlap each slot's arithmetic with the others' latency; the ~65 scalar/branch instructions k_persist spent per slot
+//     and step are gone.
+//   * the swizzle-table words of a slot's next texel are consumed at the top of the NEXT iteration (the slot keeps the
+//     three words, not their OR), so that LDS latency is off the critical path too.
+// Transition passes work as in k_persist (parked lanes, __ballot threshold, per-XCD chunked cursors, direction tables),
+// once per context.
+//
+// Restrictions (rt_api.hip dispatches everything else to k_persist): RT_FLAG_CACHE_PRIMARY, lr = (0,0,0), region 256.
+#include <hip/hip_runtime.h>
+
+#include "rt_device.hpp"
+#include "rt_kernels.hpp"
+
+namespace rtd {
+
+namespace {
+
+// nk = iterations | how the ray ended: bit 16 hit (a fresh ray on a 0, Q12: a hit with 0 iterations), bit 17 loop limit (Q8),
+// bit 18 sky, bit 19 ended by p_arm (NaN direction or first texel outside the texture).  The bits are ADDED by the step, so
+// one select chain and one add update the word.
+enum : uint32_t { K_HIT = 1u << 16, K_LIMIT = 1u << 17, K_AIR = 1u << 18, K_DEAD = 1u << 19 };
+constexpr uint32_t kEnded = 1u << 16;          // nk >= kEnded <=> the ray has ended (or the slot is empty)
+constexpr uint32_t kFreshInvalid = 1u << 24;   // counting builds: the ray's first texel was outside the texture
+constexpr uint32_t kSwzBytes = 2048;           // one swizzle table: 512 entries (0..256 used; an index is masked, never clamped)
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// One ray of trace_ray (raytrace.comp:82-183).  Direction negated (see rt_dda.hpp), (sx, sy, sz) = swizzle-table words of the
+// current texel: its swizzled voxel index is sx | sy | sz.  axis = axis of the last step (tracked for diffuse rays only: a
+// shadow ray's result is one bit).
+struct PSlot {
+    float px, py, pz, ndx, ndy, ndz, lx, ly, lz;
+    uint32_t sx, sy, sz, nk, axis;
+};
+__device__ __forceinline__ uint32_t ps_vox(const PSlot& r) { return r.sx | r.sy | r.sz; }
+__device__ __forceinline__ bool ps_special(const PSlot& r) { return (r.nk & K_DEAD) != 0u || r.nk == K_HIT; }
+
+// Path state of one context.  st = phase | level << 2 | shadow bits << 8 (bit j-1: the shadow ray of level j reached the
+// sky); ent = noise_value bytes (r, g) of the path | face id whose diffuse-table entry sits in F's direction registers << 16
+// (7 = none).
+enum : uint32_t { PP_EMPTY = 0, PP_LEVEL = 1 };
+struct PPath { uint32_t st, item, ent; };
+
+__device__ __forceinline__ float f_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t u_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// One loop iteration (raytrace.comp:109-161) with the fetched value `st` of the slot's current texel, for the lanes whose
+// ray is in flight and `enable`d; every other lane leaves the slot as it is.  No branches: a lane that does not move
+// advances by t = 0 (fma(-nd, 0, p) == p), so its position, and with it the recomputed table words, stay put.
+// GENERIC_Q: q for u of either sign (only a ray's first step can see u < 0 when lr = 0; p_arm takes that step).
+// swz = LDS byte address of the three swizzle tables (2 KiB aligned).
+template <bool GENERIC_Q, bool AXIS>
+__device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, uint32_t swz) {
+    constexpr float half = 128.0f;
+    const uint32_t nk = r.nk;
+    const bool live = enable && nk < kEnded;
+    const bool hit = st == 0u;                                   // :146 (a fresh ray on a 0: step_size 0, Q12)
+    const bool lim = nk == (uint32_t)RT_TRACE_LIMIT;             // :109 (Q8)
+    const bool go = live && !hit && !lim;
+    const uint32_t sb = (st << 23) + (126u << 23);               // float((1 << st) / 2)
+    const float sz = f_bits(sb), is = f_bits(0x7F000000u - sb);  // is == 1 / sz exactly
+    const float ux = r.px + half, uy = r.py + half, uz = r.pz + half;
+    float qx, qy, qz;                                            // (pos + 128) * muls, :94-98,119
+    if (GENERIC_Q) {
+        qx = r.ndx < 0.0f ? -ux : ux; qy = r.ndy < 0.0f ? -uy : uy; qz = r.ndz < 0.0f ? -uz : uz;
+    } else {
+        qx = f_bits((u_bits(ux) & 0x7FFFFFFFu) | (u_bits(r.ndx) & 0x80000000u));
+        qy = f_bits((u_bits(uy) & 0x7FFFFFFFu) | (u_bits(r.ndy) & 0x80000000u));
+        qz = f_bits((u_bits(uz) & 0x7FFFFFFFu) | (u_bits(r.ndz) & 0x80000000u));
+    }
+    const float mx = __builtin_fmaf(-sz, rtm_floor(qx * is), qx);   // mod(q, sz): both products exact
+    const float my = __builtin_fmaf(-sz, rtm_floor(qy * is), qy);
+    const float mz = __builtin_fmaf(-sz, rtm_floor(qz * is), qz);
+    const float tx = (0.0001f + mx) * r.lx, ty = (0.0001f + my) * r.ly, tz = (0.0001f + mz) * r.lz;   // :119
+    // :120-136 — the smallest of the three (ties: z before y before x).  The t's of a ray in flight are positive and never
+    // NaN (0.0001 + mod >= 0.0001, 1/|d| > 0), so min3 returns the value the shader's compare chain selects.
+    const float t = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+    if (AXIS) {
+        const uint32_t ax = tz == t ? 2u : (tx < ty ? 0u : 1u);
+        r.axis = go ? ax : r.axis;
+    }
+    const float te = go ? t : 0.0f;
+    r.px = __builtin_fmaf(-r.ndx, te, r.px); r.py = __builtin_fmaf(-r.ndy, te, r.py); r.pz = __builtin_fmaf(-r.ndz, te, r.pz);
+    // sky test (:138-145; with lr = 0 the subtraction p - lr is the identity)
+    const bool sky = rtm_abs(r.px) >= half || rtm_abs(r.py) >= half || rtm_abs(r.pz) >= half;
+    uint32_t d = sky ? (K_AIR | 1u) : 1u;
+    d = lim ? K_LIMIT : d;
+    d = hit ? K_HIT : d;
+    r.nk = nk + (live ? d : 0u);
+    // table words of the next fetch's texel (:137): a position inside the bounds has mod(p + 128, 256) floor-identical to
+    // (int)(p + 128), 256 = the wrap to texel 0.  4 * (p + 128) is fma(p, 4, 512) bit for bit (scaling by 4 commutes with the
+    // rounding), its integer part with the low two bits masked is the byte offset of table entry (int)(p + 128) — and the mask
+    // keeps the index of a ray that left the region (or of a lane with garbage) inside the 512-entry table.
+    const uint32_t ix = (uint32_t)(int)__builtin_fmaf(r.px, 4.0f, 512.0f), iy = (uint32_t)(int)__builtin_fmaf(r.py, 4.0f, 512.0f),
+                   iz = (uint32_t)(int)__builtin_fmaf(r.pz, 4.0f, 512.0f);
+    r.sx = *(lds_u32*)(uintptr_t)((ix & 0x7FCu) | swz);
+    r.sy = *(lds_u32*)(uintptr_t)((iy & 0x7FCu) | (swz + kSwzBytes));
+    r.sz = *(lds_u32*)(uintptr_t)((iz & 0x7FCu) | (swz + 2u * kSwzBytes));
+}
+
+}  // namespace
+
+// STK: where the albedo stack of the two paths lives — 0 = LDS (depth <= 4: three levels per path), 1 = global memory.
+template <bool COUNT, int STK>
+__global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, PersistArgs a) {
+    __shared__ uint32_t s_coarse[kCoarseWords];
+    __shared__ __attribute__((aligned(2048))) uint32_t s_swz[3 * 512];   // swizzle tables (see p_advance)
+    __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
+    __shared__ uint32_t s_stack[STK == 0 ? 2 : 1][STK == 0 ? 3 : 1][STK == 0 ? 1024 : 1];
+    const uint32_t nwork = *a.wl_count;
+    const uint32_t nitems = nwork * a.nsamples;
+    if (nitems == 0u) return;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.coarse);
+        uint4* dst = reinterpret_cast<uint4*>(s_coarse);
+        for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
+        if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
+        for (uint32_t i = threadIdx.x; i < 3u * 512u; i += 1024u) {   // entry 256 = the wrap to texel 0; 257.. are never used
+            const uint32_t ax = i >> 9, v = i & 255u;
+            s_swz[i] = ((v & 3u) << (2u * ax)) | ((v >> 2) << (6u + 6u * ax));
+        }
+    }
+    __syncthreads();
+
+    constexpr float half = 128.0f;
+    constexpr int R = 256;
+    const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
+    const uint32_t swz = (uint32_t)(uintptr_t)(lds_u32*)s_swz;   // LDS byte address of the tables
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t threshold = a.threshold;
+    const vec3 sunlight = ld3(f.sunlight);
+    const uint32_t D = (uint32_t)f.depth;
+    const uint32_t stack_levels = D > 1u ? D - 1u : 1u;
+    // minefield bytes as a buffer: a lane that needs no byte passes an out-of-range offset (no access, returns 0)
+    const auto mine_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sc.mine), (short)0, R * R * R, 0x00020000);
+
+    PSlot SA, FA, SB, FB;
+    SA.px = SA.py = SA.pz = SA.ndx = SA.ndy = SA.lx = SA.ly = SA.lz = 0.0f; SA.ndz = -1.0f;
+    SA.sx = SA.sy = SA.sz = 0u; SA.nk = K_DEAD; SA.axis = 2u;
+    FA = SA; SB = SA; FB = SA;
+    PPath PA, PB;
+    PA.st = PP_EMPTY; PA.item = 0u; PA.ent = 7u << 16;
+    PB = PA;
+
+    bool exhausted = false;
+    const uint32_t kChunk = a.chunk ? a.chunk : 128u;   // paths per cursor atomic (see k_persist)
+    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of an XCD group's share of the paths
+    uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot within the share) of path chunk_next
+    uint32_t chunk_w0 = 0, chunk_nw = 1;      // the share's slot range
+    const uint32_t home_grp = blockIdx.x & 7u;   // workgroups b and b + 8 share an XCD (round-robin dispatch; speed only)
+    uint32_t grp_tries = 0;
+
+    unsigned long long c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0, c_noise = 0;
+    unsigned long long d_iters = 0, d_pass = 0, d_pl = 0, d_live = 0;   // wave-uniform structure statistics (counting builds)
+
+    auto tally = [&](const PSlot& r) {   // exact counters of one finished ray
+        c_iter += r.nk == K_HIT ? 1u : (r.nk & 0xFFFFu);   // a fresh ray on a 0 ends inside its first iteration
+        if (r.nk & K_AIR) {
+            c_sky++;
+            int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
+            if (!wrap_texel(v3(r.px, r.py, r.pz), (float)R, &tx, &ty, &tz)) c_border++;
+        } else if (r.nk & K_LIMIT) c_limit++;
+        else c_hits++;
+        if (ps_special(r)) c_border += 1u + ((r.nk & kFreshInvalid) ? 1u : 0u);
+    };
+    // minefield value of a slot's current texel (nibble map, byte array behind it), outside the step loop
+    auto lookup = [&](const PSlot& r) -> uint32_t {
+        const uint32_t vox = ps_vox(r);
+        uint32_t st = (s_nib[vox >> 7] >> ((vox >> 4) & 4u)) & 15u;
+        if (st == kNibMixed) st = sc.mine[vox];
+        return st;
+    };
+    // head of trace_ray (:83-107) from origin (rox, roy, roz) whose first texel has the table words (tx, ty, tz); ok = that
+    // texel is inside the texture.  The slot's direction registers (nd*, l*) are already set.
+    auto arm = [&](PSlot& r, float rox, float roy, float roz, bool ok, uint32_t tx, uint32_t ty, uint32_t tz) {
+        r.px = rox; r.py = roy; r.pz = roz;
+        r.sx = tx; r.sy = ty; r.sz = tz;
+        r.axis = 2u;              // :90 — a ray that ends before its first step reports the z face
+        // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
+        const bool bad = r.ndx != r.ndx || r.ndy != r.ndy || r.ndz != r.ndz || !ok;
+        r.nk = bad ? (1u | K_DEAD | ((COUNT && !ok) ? kFreshInvalid : 0u)) : 0u;
+        const bool outside = !bad && (rox + half < 0.0f || roy + half < 0.0f || roz + half < 0.0f);
+        if (__builtin_expect(__ballot(outside) != 0ull, 0)) {   // rare (origin outside the region): see p_advance
+            uint32_t st = 0;
+            if (outside) st = lookup(r);
+            p_advance<true, true>(r, st, outside, swz);
+        }
+    };
+
+    // albedo stack of context c: packed material of surface j+2 at slot j
+    auto stack_at = [&](uint32_t c, uint32_t j) -> uint32_t {
+        if constexpr (STK == 0) return s_stack[c][j][threadIdx.x];
+        else return a.stack[((size_t)c * stack_levels + j) * a.nthreads + gtid];
+    };
+    auto stack_put = [&](uint32_t c, uint32_t j, uint32_t m) {
+        if constexpr (STK == 0) s_stack[c][j][threadIdx.x] = m;
+        else a.stack[((size_t)c * stack_levels + j) * a.nthreads + gtid] = m;
+    };
+
+    // =========================== transition pass of one context ============================================
+    auto pass = [&](PSlot& S, PSlot& F, PPath& P, const uint32_t c) {
+        const bool ended = min(S.nk, F.nk) >= kEnded;
+        const bool mine = ended && (P.st & 3u) == PP_LEVEL;
+        if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); }
+        bool begin_level = false;
+        float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
+        uint32_t snormal = 0;
+        if (mine) {
+            // Diffuse result.  The hit texel is the texel of the last fetch, so the material is mat[vox] (:150-154); the
+            // position gets the 0.001 face offset (:166-180).
+            const uint32_t level = P.st >> 2 & 31u;
+            const bool air = (F.nk & K_AIR) != 0u, special = ps_special(F);
+            const uint32_t axis = F.axis;
+            const uint32_t nrm = axis == 0u ? (F.ndx < 0.0f ? 1u : 0u) : (axis == 1u ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
+            const uint32_t neg = nrm & 1u;
+            uint32_t material = 0;
+            if ((F.nk & K_HIT) != 0u && !special) material = sc.mat[ps_vox(F)];
+            float hx = F.px, hy = F.py, hz = F.pz;
+            if (special) { hx = hy = hz = __builtin_nanf(""); }
+            const float offv = neg ? -0.001f : 0.001f;
+            hx = axis == 0u ? hx + offv : hx; hy = axis == 1u ? hy + offv : hy; hz = axis == 2u ? hz + offv : hz;
+            if (COUNT) { tally(F); tally(S); }
+            uint32_t sunbits = P.st >> 8;
+            if (S.nk & K_AIR) sunbits |= 1u << (level - 1u);               // :326-328 / :338-340
+            if (air || level == D) {
+                vec3 sky = v3(0, 0, 0);
+                if (air) {   // :331-332 / :343-345, tabulated per frame
+                    const float4 t = a.dif_lut[4u * P.ent + 3u];   // P.ent = (face << 16 | noise bytes) = the entry F walked
+                    sky = v3(t.x, t.y, t.z);
+                }
+                // L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
+                vec3 L = v3(0.0f, 0.0f, 0.0f);
+                if (sunbits >> (level - 1u) & 1u) L = vadd(L, sunlight);
+                if (air) L = vadd(L, sky);
+                for (uint32_t j = level - 1u; j >= 1u; j--) {
+                    const uint32_t pm = stack_at(c, j - 1u);
+                    vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
+                    light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
+                    vec3 acc = v3(0.0f, 0.0f, 0.0f);
+                    if (sunbits >> (j - 1u) & 1u) acc = vadd(acc, sunlight);
+                    L = vadd(acc, light2);
+                }
+                const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
+                a.pl[P.item] = make_float4(light.x, light.y, light.z, 0.0f);   // k_accumulate_paths adds a pixel's samples in order
+                P.st = PP_EMPTY;
+            } else {
+                stack_put(c, level - 1u, material);   // albedo of surface level+1
+                sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
+                P.st = PP_LEVEL | (level + 1u) << 2 | sunbits << 8;
+                begin_level = true;
+            }
+        }
+        // empty contexts pull the next paths: the wave owns a chunk of kChunk consecutive paths of its XCD group's share
+        // (one atomicAdd per chunk) and deals them out ballot-ranked (see k_persist)
+        if (!exhausted) {
+            const bool wantme = (P.st & 3u) == PP_EMPTY;
+            const uint64_t want = __ballot(wantme);
+            const uint32_t nwant = (uint32_t)__popcll(want);
+            if (nwant) {
+                if (chunk_next >= chunk_end) {
+                    for (;;) {
+                        if (grp_tries == 8u) { exhausted = true; chunk_next = chunk_end = 0u; break; }
+                        const uint32_t g = (home_grp + grp_tries) & 7u;
+                        const uint32_t w0 = (uint32_t)((uint64_t)nwork * g >> 3), nw = (uint32_t)((uint64_t)nwork * (g + 1u) >> 3) - w0;
+                        const uint32_t ng = nw * a.nsamples;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(a.cursor + 32u * g, kChunk);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base < ng) {
+                            chunk_next = base; chunk_end = base + kChunk < ng ? base + kChunk : ng;
+                            chunk_w0 = w0; chunk_nw = nw;
+                            chunk_sb = base / nw; chunk_w = base - chunk_sb * nw;   // once per chunk
+                            break;
+                        }
+                        grp_tries++;   // that group's share is handed out for good (its cursor only grows)
+                    }
+                }
+                const uint32_t take = min(nwant, chunk_end - chunk_next);
+                chunk_next += take;
+                if (wantme) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                    if (rank < take) {
+                        // (sample-in-batch, slot) of path first+rank, stepped from the chunk's running position (no division)
+                        uint32_t sb = chunk_sb, w = chunk_w + rank;
+                        while (w >= chunk_nw) { w -= chunk_nw; sb++; }
+                        w += chunk_w0;   // worklist slot
+                        const uint32_t info = a.pinfo[w];
+                        sfx = a.phx[w]; sfy = a.phy[w]; sfz = a.phz[w];
+                        snormal = info >> 28;
+                        const uint32_t wgx8 = info & 0x3FFFu, wgy8 = (info >> 14) & 0x3FFFu;
+                        P.item = sb * nwork + w;
+                        // noise_offset of this path (:298-304) and its noise_value texel (:324, :336); one integer lookup serves
+                        // every level (Q5; tests/test_math_contract.py::test_noise_value_texel_is_level_independent)
+                        const uint32_t seed = (f.seed + a.sample0 + sb) % (uint32_t)RT_NOISE_BYTES;
+                        const uint32_t by = seed / RT_NOISE_SIZE;
+                        const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
+                        const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
+                        const uint32_t se = sc.noise[ty * RT_NOISE_SIZE + tx] & 0xFFFFu;
+                        // the shadow ray's direction depends on the path's noise bytes only: one table read per path
+                        const float4 sd = a.sun_lut[2u * se], sl = a.sun_lut[2u * se + 1u];
+                        S.ndx = -sd.x; S.ndy = -sd.y; S.ndz = -sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
+                        P.ent = se | 7u << 16;
+                        P.st = PP_LEVEL | 1u << 2;
+                        begin_level = true;
+                    }
+                }
+                chunk_w += take;
+                while (chunk_w >= chunk_nw) { chunk_w -= chunk_nw; chunk_sb++; }
+            }
+        }
+        // both rays of a level (:324-330 / :336-342): noise_value, shadow ray and diffuse ray from the tables
+        if (begin_level) {
+            if (COUNT) { c_noise++; c_shadow++; c_dif++; }
+            int ix, iy, iz;
+            const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
+            const uint32_t tx = s_swz[ix], ty = s_swz[512 + iy], tz = s_swz[1024 + iz];
+            // F's direction registers still hold the entry of the path's previous level; it repeats whenever the next
+            // surface has the same face
+            const uint32_t se = P.ent & 0xFFFFu;
+            if (snormal != P.ent >> 16) {
+                const uint32_t di = 4u * ((snormal << 16) | se);
+                const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
+                F.ndx = -d2.x; F.ndy = -d2.y; F.ndz = -d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
+                P.ent = se | snormal << 16;
+            }
+            arm(S, sfx, sfy, sfz, ok, tx, ty, tz);
+            arm(F, sfx, sfy, sfz, ok, tx, ty, tz);
+        }
+    };
+
+    uint64_t idleA = 0ull, idleB = 0ull;   // lanes whose context is empty for good (no paths left)
+    for (;;) {
+        uint64_t parkA, parkB;
+        for (;;) {
+            // a context parks when both its rays have ended; when `threshold` lanes have one kind parked, that kind's pass runs
+            const uint64_t eA = __ballot(min(SA.nk, FA.nk) >= kEnded), eB = __ballot(min(SB.nk, FB.nk) >= kEnded);
+            parkA = eA & ~idleA; parkB = eB & ~idleB;
+            if ((uint32_t)__popcll(parkA) >= threshold || (uint32_t)__popcll(parkB) >= threshold || (eA & eB) == ~0ull) break;
+            if (COUNT) { d_iters++; d_live += (uint32_t)__popcll(~eA) + (uint32_t)__popcll(~eB); }
+            // ---- one step of all four slots: nibble reads, then byte loads, then the arithmetic ----
+            const uint32_t v0 = ps_vox(SA), v1 = ps_vox(FA), v2 = ps_vox(SB), v3_ = ps_vox(FB);
+            const uint32_t w0 = s_nib[v0 >> 7], w1 = s_nib[v1 >> 7], w2 = s_nib[v2 >> 7], w3 = s_nib[v3_ >> 7];
+            uint32_t t0 = __builtin_amdgcn_ubfe(w0, (v0 >> 4) & 4u, 4u), t1 = __builtin_amdgcn_ubfe(w1, (v1 >> 4) & 4u, 4u),
+                     t2 = __builtin_amdgcn_ubfe(w2, (v2 >> 4) & 4u, 4u), t3 = __builtin_amdgcn_ubfe(w3, (v3_ >> 4) & 4u, 4u);
+            const bool g0 = SA.nk < kEnded && t0 == kNibMixed, g1 = FA.nk < kEnded && t1 == kNibMixed,
+                       g2 = SB.nk < kEnded && t2 == kNibMixed, g3 = FB.nk < kEnded && t3 == kNibMixed;
+            const uint32_t b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
+            const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g1 ? v1 : 0xFFFFFFFFu, 0, 0);
+            const uint32_t b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
+            const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g3 ? v3_ : 0xFFFFFFFFu, 0, 0);
+            t0 = g0 ? b0 : t0; t1 = g1 ? b1 : t1; t2 = g2 ? b2 : t2; t3 = g3 ? b3 : t3;
+            p_advance<false, false>(SA, t0, true, swz);
+            p_advance<false, true>(FA, t1, true, swz);
+            p_advance<false, false>(SB, t2, true, swz);
+            p_advance<false, true>(FB, t3, true, swz);
+        }
+        if ((parkA | parkB) == 0ull) break;   // nothing in flight, nothing parked, no paths left
+        if ((uint32_t)__popcll(parkA) >= (uint32_t)__popcll(parkB)) pass(SA, FA, PA, 0u); else pass(SB, FB, PB, 1u);
+        if (exhausted) { idleA = __ballot((PA.st & 3u) == PP_EMPTY); idleB = __ballot((PB.st & 3u) == PP_EMPTY); }
+    }
+    if (COUNT) {
+        DevCounters* cn = a.counters;
+        const unsigned long long rays = c_shadow + c_dif;
+        wave_add(&cn->rays, rays); wave_add(&cn->rays_shadow, c_shadow);
+        wave_add(&cn->rays_diffuse, c_dif); wave_add(&cn->iterations, c_iter); wave_add(&cn->minefield_fetches, rays + c_iter);
+        wave_add(&cn->hits, c_hits); wave_add(&cn->material_fetches, c_hits); wave_add(&cn->sky_exits, c_sky);
+        wave_add(&cn->limit_exits, c_limit); wave_add(&cn->border_fetches, c_border); wave_add(&cn->noise_fetches, c_noise);
+        if (lane == 0) {
+            atomicAdd(&cn->dbg_loop_iters, d_iters); atomicAdd(&cn->dbg_f_lanes, d_live);
+            atomicAdd(&cn->dbg_passes, d_pass); atomicAdd(&cn->dbg_pass_lanes, d_pl);
+        }
+    }
+}
+
+hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nworkgroups,
+                        hipStream_t st) {
+    if (f.logr != 8 || f.lr_zero == 0) return hipErrorInvalidValue;
+    const dim3 grid(nworkgroups), block(1024);
+    const bool lds_stack = f.depth <= 4;
+    if (lds_stack) {
+        if (count) hipLaunchKernelGGL((k_paths<true, 0>), grid, block, 0, st, sc, f, pl, a);
+        else hipLaunchKernelGGL((k_paths<false, 0>), grid, block, 0, st, sc, f, pl, a);
+    } else {
+        if (count) hipLaunchKernelGGL((k_paths<true, 1>), grid, block, 0, st, sc, f, pl, a);
+        else hipLaunchKernelGGL((k_paths<false, 1>), grid, block, 0, st, sc, f, pl, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rtd

@@ -52,6 +52,19 @@ def _compare(gpu, cpu, gcn=None, ccn=None):
         assert gd == cd, "counters differ: %s" % {k: (gd[k], cd[k]) for k in gd if gd[k] != cd[k]}
 
 
+def _cached_counters(mats, mine, noise, u, W, H, spp, depth, ccn, **kw):
+    """Counters the oracle implies for a frame rendered with RT_FLAG_CACHE_PRIMARY: the primary ray (seed-independent) is
+    traced once per pixel instead of once per sample, everything else is unchanged."""
+    _, c0 = po.render(mats, mine, noise, u, W, H, 1, 0, **kw)      # the primary rays of one sample
+    d, p = ccn.as_dict(), c0.as_dict()
+    for k in ("rays", "rays_primary", "iterations", "minefield_fetches", "material_fetches", "hits", "sky_exits", "limit_exits",
+              "border_fetches"):
+        d[k] -= (spp - 1) * p[k]
+    return d
+
+
+PATH_KERNELS = [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2, abi.RT_KERNEL_PATHS]
+
 CASES = [
     # W, H, spp, depth
     (64, 64, 1, 2),      # the reference frame (1 spp, 2 levels)
@@ -136,7 +149,7 @@ def test_primary_cache_same_pixels(procedural_region, blue_noise, W, H, spp, dep
     assert gcn.rays == ccn.rays - (spp - 1) * W * H
 
 
-@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2])
+@pytest.mark.parametrize("kernel", PATH_KERNELS)
 @pytest.mark.parametrize("W,H", [(96, 64), (100, 60)])
 def test_tile_split_contexts_reassemble_to_the_full_frame(procedural_region, blue_noise, W, H, kernel):
     """Multi-GPU layout on one GPU: two contexts render the even / odd 8x8 tiles (tile_world = 2), their tile-major
@@ -449,22 +462,24 @@ def test_region_1024_matches_oracle(blue_noise, native_built):
             _compare(gpu, cpu, gcn, ccn)
 
 
-@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2])
-@pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 3, 2), (5, 3, 2, 4), (9, 17, 1, abi.MAX_DEPTH), (24, 16, 37, 3)])
+@pytest.mark.parametrize("kernel", PATH_KERNELS)
+@pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 3, 2), (5, 3, 2, 4), (9, 17, 1, abi.MAX_DEPTH), (24, 16, 37, 3), (40, 24, 2, 5), (40, 24, 2, 8), (40, 24, 2, 9)])
 def test_edge_shapes_match_oracle(procedural_region, blue_noise, kernel, W, H, spp, depth):
     """Frames smaller than one tile / one wave, the maximum depth, and more samples than lanes."""
     mats, mine = procedural_region
     u = _uniforms(seed=77)
     cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
-    for flags in (abi.RT_FLAG_COUNTERS, abi.RT_FLAG_CACHE_PRIMARY):
+    for flags in (abi.RT_FLAG_COUNTERS, abi.RT_FLAG_CACHE_PRIMARY, abi.RT_FLAG_COUNTERS | abi.RT_FLAG_CACHE_PRIMARY):
         gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=flags)
-        if flags & abi.RT_FLAG_CACHE_PRIMARY:
-            _compare(gpu, cpu)
-        else:
+        if flags == abi.RT_FLAG_COUNTERS:
             _compare(gpu, cpu, gcn, ccn)
+        else:
+            _compare(gpu, cpu)
+            if flags & abi.RT_FLAG_COUNTERS:
+                assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
 
 
-@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2])
+@pytest.mark.parametrize("kernel", PATH_KERNELS)
 def test_sample_batches_accumulate_in_order(procedural_region, blue_noise, kernel, monkeypatch):
     """spp larger than one launch holds: RT_PERSIST_BATCH forces 4 launches of 3 + 3 + 3 + 1 samples; the per-pixel sum must
     still run in sample order (same bits as one launch and as the oracle)."""
@@ -496,7 +511,7 @@ def test_per_frame_tables_follow_the_sun(procedural_region, blue_noise):
 
 
 @pytest.mark.parametrize("threshold,rmin", [(1, 1), (64, 128), (17, 3)])
-@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2])
+@pytest.mark.parametrize("kernel", PATH_KERNELS)
 def test_scheduling_parameters_do_not_change_results(procedural_region, blue_noise, kernel, threshold, rmin, monkeypatch):
     """The parked-lane threshold of the transition pass and the re-arm trigger only regroup the work: planes and counters
     stay those of the oracle at the extremes too (pass per finished lane / only when the whole wave is parked)."""
@@ -508,8 +523,9 @@ def test_scheduling_parameters_do_not_change_results(procedural_region, blue_noi
     cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
     gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel)
     _compare(gpu, cpu, gcn, ccn)
-    gpu, _ = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=abi.RT_FLAG_CACHE_PRIMARY)
+    gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS)
     _compare(gpu, cpu)
+    assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
 
 
 def test_headline_frame_equals_the_oracle(procedural_region, blue_noise):
@@ -519,8 +535,13 @@ def test_headline_frame_equals_the_oracle(procedural_region, blue_noise):
     W, H, spp, depth = 1920, 1080, 64, 4
     u = render.camera_uniforms((-30.0, -128.0, 100.0), np.pi / 2, 0.0, 0.0, seed=1)
     cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
-    for kernel in (abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2):
+    for kernel in PATH_KERNELS:
         gpu, _ = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=abi.RT_FLAG_CACHE_PRIMARY)
         _compare(gpu, cpu)
     gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, abi.RT_KERNEL_DEFAULT)
     _compare(gpu, cpu, gcn, ccn)
+    # the counting build of the kernel the benchmark times (cached primaries): exact ray / iteration / fetch counts
+    gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, abi.RT_KERNEL_DEFAULT,
+                           flags=abi.RT_FLAG_COUNTERS | abi.RT_FLAG_CACHE_PRIMARY)
+    _compare(gpu, cpu)
+    assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
