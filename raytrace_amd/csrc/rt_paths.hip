@@ -1,20 +1,25 @@
 // rt_paths.hip — k_paths, the path kernel RT_KERNEL_DEFAULT runs for cached-primary frames with lr = 0.
 //
 // Same work, same values as k_persist (rt_persist.hip); what differs is how much of it a wave keeps in flight and how the
-// step loop is issued:
+// instructions are spent (measured on gfx950: this path is VALU-issue bound — tools/ubench/valu_rate.hip):
 //   * a lane carries TWO paths (contexts A and B), each with the level's shadow ray and diffuse ray in their own ray slots:
 //     four independent fetch chains per lane instead of two.  k_persist ran at an LDS-pinned four waves per SIMD with 75 of
 //     its 128 VGPRs and its waves parked at s_waitcnt half of their life (round-1 counters); the idle registers now hold
 //     the second path.
 //   * the step loop is ONE basic block: every slot's step is predicated with selects instead of exec-mask branches and the
 //     byte behind a "mixed" nibble-map entry is a buffer load whose offset is out of range for lanes that do not need it
-//     (no memory access, returns 0).  The compiler can therefore issue the four nibble reads, then the four byte loads, and
-//     overlap each slot's arithmetic with the others' latency; the ~65 scalar/branch instructions k_persist spent per slot
-//     and step are gone.
+//     (no memory access, returns 0).  The compiler issues the four nibble reads, then the four byte loads, and overlaps each
+//     slot's arithmetic with the others' latency; the ~65 scalar/branch instructions k_persist spent per slot and step
+//     are gone.
 //   * the swizzle-table words of a slot's next texel are consumed at the top of the NEXT iteration (the slot keeps the
 //     three words, not their OR), so that LDS latency is off the critical path too.
-// Transition passes work as in k_persist (parked lanes, __ballot threshold, per-XCD chunked cursors, direction tables),
-// once per context.
+//   * a ray's bookkeeping word counts DOWN from the loop limit, so "in flight and below the limit" is one compare; a ray that
+//     stops without reaching the sky is only marked ENDED — whether that was a hit, the loop limit or a fresh ray on a 0 is
+//     read off the word (and, for the limit, one more lookup) when the transition pass consumes it.
+// Transition passes work as in k_persist (parked lanes, __ballot threshold, per-XCD chunked cursors, direction tables), once
+// per context.  (Passes specialised by what the parked level needs — "end the path and pull the next" vs "start another
+// level" — were built and measured: 6.08 ms against 5.3 ms for the combined pass; twice as many passes, each with its own
+// chain of dependent loads, cost more than the better-filled halves saved.)
 //
 // Restrictions (rt_api.hip dispatches everything else to k_persist): RT_FLAG_CACHE_PRIMARY, lr = (0,0,0), region 256.
 #include <hip/hip_runtime.h>
@@ -26,11 +31,12 @@ namespace rtd {
 
 namespace {
 
-// nk = iterations | how the ray ended: bit 16 hit (a fresh ray on a 0, Q12: a hit with 0 iterations), bit 17 loop limit (Q8),
-// bit 18 sky, bit 19 ended by p_arm (NaN direction or first texel outside the texture).  The bits are ADDED by the step, so
-// one select chain and one add update the word.
-enum : uint32_t { K_HIT = 1u << 16, K_LIMIT = 1u << 17, K_AIR = 1u << 18, K_DEAD = 1u << 19 };
-constexpr uint32_t kEnded = 1u << 16;          // nk >= kEnded <=> the ray has ended (or the slot is empty)
+// nk = iterations LEFT before the loop limit (raytrace.comp:109; 2048 for a fresh ray) | flags:
+//   K_END   the ray has ended (or the slot is empty)
+//   K_AIR   ... by leaving the region (:138-145)
+//   K_DEAD  ... in p_arm: NaN direction or first texel outside the texture (one iteration, border fetch, Q12)
+// A ray in flight has 1 <= nk <= 2048; nk == 0 is a ray at the loop limit (its next iteration ends it either way).
+enum : uint32_t { K_END = 1u << 16, K_AIR = 1u << 17, K_DEAD = 1u << 18 };
 constexpr uint32_t kFreshInvalid = 1u << 24;   // counting builds: the ray's first texel was outside the texture
 constexpr uint32_t kSwzBytes = 2048;           // one swizzle table: 512 entries (0..256 used; an index is masked, never clamped)
 
@@ -44,12 +50,13 @@ struct PSlot {
     uint32_t sx, sy, sz, nk, axis;
 };
 __device__ __forceinline__ uint32_t ps_vox(const PSlot& r) { return r.sx | r.sy | r.sz; }
-__device__ __forceinline__ bool ps_special(const PSlot& r) { return (r.nk & K_DEAD) != 0u || r.nk == K_HIT; }
+__device__ __forceinline__ bool ps_running(uint32_t nk) { return nk - 1u < (uint32_t)RT_TRACE_LIMIT; }   // 1 <= nk <= 2048
 
-// Path state of one context.  st = phase | level << 2 | shadow bits << 8 (bit j-1: the shadow ray of level j reached the
-// sky); ent = noise_value bytes (r, g) of the path | face id whose diffuse-table entry sits in F's direction registers << 16
-// (7 = none).
-enum : uint32_t { PP_EMPTY = 0, PP_LEVEL = 1 };
+// Path state of one context.  st = shadow bits (bit j-1: the shadow ray of level j reached the sky) | PP_FINAL | level << 20
+// (level 0 = no path); PP_FINAL (the same bit as K_AIR) = the level in flight is the path's last (level == depth), or there is
+// no path: (F.nk | st) & K_AIR says whether the parked context needs pass_finish or pass_continue.
+// ent = noise_value bytes (r, g) of the path | face id whose diffuse-table entry sits in F's direction registers << 16 (7 = none).
+constexpr uint32_t PP_FINAL = K_AIR;
 struct PPath { uint32_t st, item, ent; };
 
 __device__ __forceinline__ float f_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
@@ -64,10 +71,9 @@ template <bool GENERIC_Q, bool AXIS>
 __device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, uint32_t swz) {
     constexpr float half = 128.0f;
     const uint32_t nk = r.nk;
-    const bool live = enable && nk < kEnded;
-    const bool hit = st == 0u;                                   // :146 (a fresh ray on a 0: step_size 0, Q12)
-    const bool lim = nk == (uint32_t)RT_TRACE_LIMIT;             // :109 (Q8)
-    const bool go = live && !hit && !lim;
+    // in flight and below the loop limit (:109), on a value > 0 (:146): the ray moves.  Otherwise it has ended (or does so now:
+    // hit, limit, or a fresh ray on a 0 — the pass tells them apart).
+    const bool go = enable && ps_running(nk) && st != 0u;
     const uint32_t sb = (st << 23) + (126u << 23);               // float((1 << st) / 2)
     const float sz = f_bits(sb), is = f_bits(0x7F000000u - sb);  // is == 1 / sz exactly
     const float ux = r.px + half, uy = r.py + half, uz = r.pz + half;
@@ -92,12 +98,11 @@ __device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, ui
     }
     const float te = go ? t : 0.0f;
     r.px = __builtin_fmaf(-r.ndx, te, r.px); r.py = __builtin_fmaf(-r.ndy, te, r.py); r.pz = __builtin_fmaf(-r.ndz, te, r.pz);
-    // sky test (:138-145; with lr = 0 the subtraction p - lr is the identity)
-    const bool sky = rtm_abs(r.px) >= half || rtm_abs(r.py) >= half || rtm_abs(r.pz) >= half;
-    uint32_t d = sky ? (K_AIR | 1u) : 1u;
-    d = lim ? K_LIMIT : d;
-    d = hit ? K_HIT : d;
-    r.nk = nk + (live ? d : 0u);
+    // sky test (:138-145; with lr = 0 the subtraction p - lr is the identity).  max ignores a NaN operand like the three
+    // compares would.
+    const bool sky = __builtin_fmaxf(__builtin_fmaxf(rtm_abs(r.px), rtm_abs(r.py)), rtm_abs(r.pz)) >= half;
+    const uint32_t moved = nk + (sky ? (K_AIR | K_END) - 1u : 0xFFFFFFFFu);
+    r.nk = go ? moved : (nk | K_END);
     // table words of the next fetch's texel (:137): a position inside the bounds has mod(p + 128, 256) floor-identical to
     // (int)(p + 128), 256 = the wrap to texel 0.  4 * (p + 128) is fma(p, 4, 512) bit for bit (scaling by 4 commutes with the
     // rounding), its integer part with the low two bits masked is the byte offset of table entry (int)(p + 128) — and the mask
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     const uint32_t swz = (uint32_t)(uintptr_t)(lds_u32*)s_swz;   // LDS byte address of the tables
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * 1024u + threadIdx.x;
-    const uint32_t threshold = a.threshold;
+    const uint32_t threshold = a.threshold;   // parked lanes of one context kind that trigger its transition pass
     const vec3 sunlight = ld3(f.sunlight);
     const uint32_t D = (uint32_t)f.depth;
     const uint32_t stack_levels = D > 1u ? D - 1u : 1u;
@@ -148,10 +153,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
 
     PSlot SA, FA, SB, FB;
     SA.px = SA.py = SA.pz = SA.ndx = SA.ndy = SA.lx = SA.ly = SA.lz = 0.0f; SA.ndz = -1.0f;
-    SA.sx = SA.sy = SA.sz = 0u; SA.nk = K_DEAD; SA.axis = 2u;
+    SA.sx = SA.sy = SA.sz = 0u; SA.nk = K_DEAD | K_END; SA.axis = 2u;
     FA = SA; SB = SA; FB = SA;
     PPath PA, PB;
-    PA.st = PP_EMPTY; PA.item = 0u; PA.ent = 7u << 16;
+    PA.st = PP_FINAL; PA.item = 0u; PA.ent = 7u << 16;
     PB = PA;
 
     bool exhausted = false;
@@ -163,24 +168,40 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     uint32_t grp_tries = 0;
 
     unsigned long long c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0, c_noise = 0;
-    unsigned long long d_iters = 0, d_pass = 0, d_pl = 0, d_live = 0;   // wave-uniform structure statistics (counting builds)
+    unsigned long long d_iters = 0, d_passf = 0, d_plf = 0, d_live = 0;   // wave-uniform structure statistics (counting builds)
 
-    auto tally = [&](const PSlot& r) {   // exact counters of one finished ray
-        c_iter += r.nk == K_HIT ? 1u : (r.nk & 0xFFFFu);   // a fresh ray on a 0 ends inside its first iteration
-        if (r.nk & K_AIR) {
-            c_sky++;
-            int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
-            if (!wrap_texel(v3(r.px, r.py, r.pz), (float)R, &tx, &ty, &tz)) c_border++;
-        } else if (r.nk & K_LIMIT) c_limit++;
-        else c_hits++;
-        if (ps_special(r)) c_border += 1u + ((r.nk & kFreshInvalid) ? 1u : 0u);
-    };
     // minefield value of a slot's current texel (nibble map, byte array behind it), outside the step loop
     auto lookup = [&](const PSlot& r) -> uint32_t {
         const uint32_t vox = ps_vox(r);
         uint32_t st = (s_nib[vox >> 7] >> ((vox >> 4) & 4u)) & 15u;
         if (st == kNibMixed) st = sc.mine[vox];
         return st;
+    };
+    // How an ENDED ray that did not reach the sky stopped: 0 = hit (:146-160), 1 = loop limit (Q8: a non-air hit with
+    // material 0), 2 = special (Q12: fresh ray on a 0, NaN direction, first texel outside the texture: NaN position, material 0).
+    // The limit case needs the value of the ray's texel once more (nk == K_END: no iterations left) — practically never taken.
+    auto stop_kind = [&](const PSlot& r) -> uint32_t {
+        const uint32_t left = r.nk & 0xFFFFu;
+        uint32_t kind = ((r.nk & K_DEAD) != 0u || left == (uint32_t)RT_TRACE_LIMIT) ? 2u : 0u;
+        const bool at_limit = kind == 0u && left == 0u;
+        if (__builtin_expect(__ballot(at_limit) != 0ull, 0)) {
+            if (at_limit && lookup(r) != 0u) kind = 1u;
+        }
+        return kind;
+    };
+    auto tally = [&](const PSlot& r) {   // exact counters of one finished ray
+        const uint32_t left = r.nk & 0xFFFFu;
+        if (r.nk & K_AIR) {
+            c_iter += (uint32_t)RT_TRACE_LIMIT - left;
+            c_sky++;
+            int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
+            if (!wrap_texel(v3(r.px, r.py, r.pz), (float)R, &tx, &ty, &tz)) c_border++;
+        } else {
+            const uint32_t kind = stop_kind(r);
+            c_iter += kind == 2u ? 1u : (uint32_t)RT_TRACE_LIMIT - left;   // a ray that is special ends inside its first iteration
+            if (kind == 1u) c_limit++; else c_hits++;
+            if (kind == 2u) c_border += 1u + ((r.nk & kFreshInvalid) ? 1u : 0u);
+        }
     };
     // head of trace_ray (:83-107) from origin (rox, roy, roz) whose first texel has the table words (tx, ty, tz); ok = that
     // texel is inside the texture.  The slot's direction registers (nd*, l*) are already set.
@@ -190,7 +211,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         r.axis = 2u;              // :90 — a ray that ends before its first step reports the z face
         // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
         const bool bad = r.ndx != r.ndx || r.ndy != r.ndy || r.ndz != r.ndz || !ok;
-        r.nk = bad ? (1u | K_DEAD | ((COUNT && !ok) ? kFreshInvalid : 0u)) : 0u;
+        r.nk = bad ? (K_DEAD | K_END | ((COUNT && !ok) ? kFreshInvalid : 0u)) : (uint32_t)RT_TRACE_LIMIT;
         const bool outside = !bad && (rox + half < 0.0f || roy + half < 0.0f || roz + half < 0.0f);
         if (__builtin_expect(__ballot(outside) != 0ull, 0)) {   // rare (origin outside the region): see p_advance
             uint32_t st = 0;
@@ -209,32 +230,41 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         else a.stack[((size_t)c * stack_levels + j) * a.nthreads + gtid] = m;
     };
 
+    // both rays of a level (:324-330 / :336-342) from the surface point (sfx, sfy, sfz) with face id snormal: the shadow ray's
+    // direction is in S's registers for the whole path, the diffuse ray's comes from the table
+    auto begin_level = [&](PSlot& S, PSlot& F, PPath& P, float sfx, float sfy, float sfz, uint32_t snormal) {
+        if (COUNT) { c_noise++; c_shadow++; c_dif++; }
+        int ix, iy, iz;
+        const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
+        const uint32_t tx = s_swz[ix], ty = s_swz[512 + iy], tz = s_swz[1024 + iz];
+        // F's direction registers still hold the entry of the path's previous level; it repeats whenever the next surface has
+        // the same face
+        const uint32_t se = P.ent & 0xFFFFu;
+        if (snormal != P.ent >> 16) {
+            const uint32_t di = 4u * ((snormal << 16) | se);
+            const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
+            F.ndx = -d2.x; F.ndy = -d2.y; F.ndz = -d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
+            P.ent = se | snormal << 16;
+        }
+        arm(S, sfx, sfy, sfz, ok, tx, ty, tz);
+        arm(F, sfx, sfy, sfz, ok, tx, ty, tz);
+    };
+
     // =========================== transition pass of one context ============================================
     auto pass = [&](PSlot& S, PSlot& F, PPath& P, const uint32_t c) {
-        const bool ended = min(S.nk, F.nk) >= kEnded;
-        const bool mine = ended && (P.st & 3u) == PP_LEVEL;
-        if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); }
-        bool begin_level = false;
+        const bool ended = min(S.nk, F.nk) >= K_END;
+        const uint32_t level = P.st >> 20;
+        const bool mine = ended && level != 0u;
+        if (COUNT) { d_passf++; d_plf += (uint32_t)__popcll(__ballot(mine)); }
+        bool start = false;
         float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
         uint32_t snormal = 0;
         if (mine) {
-            // Diffuse result.  The hit texel is the texel of the last fetch, so the material is mat[vox] (:150-154); the
-            // position gets the 0.001 face offset (:166-180).
-            const uint32_t level = P.st >> 2 & 31u;
-            const bool air = (F.nk & K_AIR) != 0u, special = ps_special(F);
-            const uint32_t axis = F.axis;
-            const uint32_t nrm = axis == 0u ? (F.ndx < 0.0f ? 1u : 0u) : (axis == 1u ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
-            const uint32_t neg = nrm & 1u;
-            uint32_t material = 0;
-            if ((F.nk & K_HIT) != 0u && !special) material = sc.mat[ps_vox(F)];
-            float hx = F.px, hy = F.py, hz = F.pz;
-            if (special) { hx = hy = hz = __builtin_nanf(""); }
-            const float offv = neg ? -0.001f : 0.001f;
-            hx = axis == 0u ? hx + offv : hx; hy = axis == 1u ? hy + offv : hy; hz = axis == 2u ? hz + offv : hz;
             if (COUNT) { tally(F); tally(S); }
-            uint32_t sunbits = P.st >> 8;
+            uint32_t sunbits = P.st & 0xFFFFu;
             if (S.nk & K_AIR) sunbits |= 1u << (level - 1u);               // :326-328 / :338-340
-            if (air || level == D) {
+            const bool air = (F.nk & K_AIR) != 0u;
+            if (((F.nk | P.st) & K_AIR) != 0u) {   // sky exit or last level: the path ends
                 vec3 sky = v3(0, 0, 0);
                 if (air) {   // :331-332 / :343-345, tabulated per frame
                     const float4 t = a.dif_lut[4u * P.ent + 3u];   // P.ent = (face << 16 | noise bytes) = the entry F walked
@@ -254,18 +284,29 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
                 }
                 const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
                 a.pl[P.item] = make_float4(light.x, light.y, light.z, 0.0f);   // k_accumulate_paths adds a pixel's samples in order
-                P.st = PP_EMPTY;
+                P.st = PP_FINAL;
             } else {
+                // Diffuse result.  The hit texel is the texel of the last fetch, so the material is mat[vox] (:150-154); the
+                // position gets the 0.001 face offset (:166-180).
+                const uint32_t kind = stop_kind(F);
+                const uint32_t axis = F.axis;
+                const uint32_t nrm = axis == 0u ? (F.ndx < 0.0f ? 1u : 0u) : (axis == 1u ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
+                uint32_t material = 0;
+                if (kind == 0u) material = sc.mat[ps_vox(F)];
+                float hx = F.px, hy = F.py, hz = F.pz;
+                if (kind == 2u) { hx = hy = hz = __builtin_nanf(""); }
+                const float offv = (nrm & 1u) ? -0.001f : 0.001f;
+                hx = axis == 0u ? hx + offv : hx; hy = axis == 1u ? hy + offv : hy; hz = axis == 2u ? hz + offv : hz;
                 stack_put(c, level - 1u, material);   // albedo of surface level+1
+                P.st = sunbits | (level + 1u) << 20 | (level + 1u == D ? PP_FINAL : 0u);
                 sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
-                P.st = PP_LEVEL | (level + 1u) << 2 | sunbits << 8;
-                begin_level = true;
+                start = true;
             }
         }
-        // empty contexts pull the next paths: the wave owns a chunk of kChunk consecutive paths of its XCD group's share
-        // (one atomicAdd per chunk) and deals them out ballot-ranked (see k_persist)
+        // contexts without a path pull the next ones: the wave owns a chunk of kChunk consecutive paths of its XCD group's
+        // share (one atomicAdd per chunk) and deals them out ballot-ranked (see k_persist)
         if (!exhausted) {
-            const bool wantme = (P.st & 3u) == PP_EMPTY;
+            const bool wantme = ended && (P.st >> 20) == 0u;
             const uint64_t want = __ballot(wantme);
             const uint32_t nwant = (uint32_t)__popcll(want);
             if (nwant) {
@@ -312,32 +353,15 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
                         const float4 sd = a.sun_lut[2u * se], sl = a.sun_lut[2u * se + 1u];
                         S.ndx = -sd.x; S.ndy = -sd.y; S.ndz = -sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
                         P.ent = se | 7u << 16;
-                        P.st = PP_LEVEL | 1u << 2;
-                        begin_level = true;
+                        P.st = 1u << 20 | (D == 1u ? PP_FINAL : 0u);
+                        start = true;
                     }
                 }
                 chunk_w += take;
                 while (chunk_w >= chunk_nw) { chunk_w -= chunk_nw; chunk_sb++; }
             }
         }
-        // both rays of a level (:324-330 / :336-342): noise_value, shadow ray and diffuse ray from the tables
-        if (begin_level) {
-            if (COUNT) { c_noise++; c_shadow++; c_dif++; }
-            int ix, iy, iz;
-            const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
-            const uint32_t tx = s_swz[ix], ty = s_swz[512 + iy], tz = s_swz[1024 + iz];
-            // F's direction registers still hold the entry of the path's previous level; it repeats whenever the next
-            // surface has the same face
-            const uint32_t se = P.ent & 0xFFFFu;
-            if (snormal != P.ent >> 16) {
-                const uint32_t di = 4u * ((snormal << 16) | se);
-                const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
-                F.ndx = -d2.x; F.ndy = -d2.y; F.ndz = -d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
-                P.ent = se | snormal << 16;
-            }
-            arm(S, sfx, sfy, sfz, ok, tx, ty, tz);
-            arm(F, sfx, sfy, sfz, ok, tx, ty, tz);
-        }
+        if (start) begin_level(S, F, P, sfx, sfy, sfz, snormal);
     };
 
     uint64_t idleA = 0ull, idleB = 0ull;   // lanes whose context is empty for good (no paths left)
@@ -345,7 +369,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         uint64_t parkA, parkB;
         for (;;) {
             // a context parks when both its rays have ended; when `threshold` lanes have one kind parked, that kind's pass runs
-            const uint64_t eA = __ballot(min(SA.nk, FA.nk) >= kEnded), eB = __ballot(min(SB.nk, FB.nk) >= kEnded);
+            const uint64_t eA = __ballot(min(SA.nk, FA.nk) >= K_END), eB = __ballot(min(SB.nk, FB.nk) >= K_END);
             parkA = eA & ~idleA; parkB = eB & ~idleB;
             if ((uint32_t)__popcll(parkA) >= threshold || (uint32_t)__popcll(parkB) >= threshold || (eA & eB) == ~0ull) break;
             if (COUNT) { d_iters++; d_live += (uint32_t)__popcll(~eA) + (uint32_t)__popcll(~eB); }
@@ -354,8 +378,8 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             const uint32_t w0 = s_nib[v0 >> 7], w1 = s_nib[v1 >> 7], w2 = s_nib[v2 >> 7], w3 = s_nib[v3_ >> 7];
             uint32_t t0 = __builtin_amdgcn_ubfe(w0, (v0 >> 4) & 4u, 4u), t1 = __builtin_amdgcn_ubfe(w1, (v1 >> 4) & 4u, 4u),
                      t2 = __builtin_amdgcn_ubfe(w2, (v2 >> 4) & 4u, 4u), t3 = __builtin_amdgcn_ubfe(w3, (v3_ >> 4) & 4u, 4u);
-            const bool g0 = SA.nk < kEnded && t0 == kNibMixed, g1 = FA.nk < kEnded && t1 == kNibMixed,
-                       g2 = SB.nk < kEnded && t2 == kNibMixed, g3 = FB.nk < kEnded && t3 == kNibMixed;
+            const bool g0 = ps_running(SA.nk) && t0 == kNibMixed, g1 = ps_running(FA.nk) && t1 == kNibMixed,
+                       g2 = ps_running(SB.nk) && t2 == kNibMixed, g3 = ps_running(FB.nk) && t3 == kNibMixed;
             const uint32_t b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
             const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g1 ? v1 : 0xFFFFFFFFu, 0, 0);
             const uint32_t b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
@@ -368,7 +392,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         }
         if ((parkA | parkB) == 0ull) break;   // nothing in flight, nothing parked, no paths left
         if ((uint32_t)__popcll(parkA) >= (uint32_t)__popcll(parkB)) pass(SA, FA, PA, 0u); else pass(SB, FB, PB, 1u);
-        if (exhausted) { idleA = __ballot((PA.st & 3u) == PP_EMPTY); idleB = __ballot((PB.st & 3u) == PP_EMPTY); }
+        if (exhausted) { idleA = __ballot((PA.st >> 20) == 0u); idleB = __ballot((PB.st >> 20) == 0u); }
     }
     if (COUNT) {
         DevCounters* cn = a.counters;
@@ -379,7 +403,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         wave_add(&cn->limit_exits, c_limit); wave_add(&cn->border_fetches, c_border); wave_add(&cn->noise_fetches, c_noise);
         if (lane == 0) {
             atomicAdd(&cn->dbg_loop_iters, d_iters); atomicAdd(&cn->dbg_f_lanes, d_live);
-            atomicAdd(&cn->dbg_passes, d_pass); atomicAdd(&cn->dbg_pass_lanes, d_pl);
+            atomicAdd(&cn->dbg_passes, d_passf); atomicAdd(&cn->dbg_pass_lanes, d_plf);
         }
     }
 }
