@@ -108,6 +108,8 @@ typedef enum RtKernel {
 #define RT_FLAG_CACHE_PRIMARY 0x2u  /* spp>1: trace the (seed-independent) primary ray once per pixel    */
 #define RT_FLAG_TIMING        0x4u  /* bracket the traversal-kernel launches with HIP events (RtTiming.trace_ms)  */
 #define RT_FLAG_TIMING_ALL    0xCu  /* ... and every other launch as well (RtTiming.shade_ms); includes RT_FLAG_TIMING */
+#define RT_FLAG_TRUSTED_WORLD 0x10u /* rt_upload_slice: the host vouches that every minefield value is <= 30 (the reference
+                                       writes 0..6); the slab is applied without the device->host round trip of the check */
 
 /*
  * RtConfig — replaces the compile-time window constants (constants.rs:9-10) and adds the
@@ -203,7 +205,8 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
 /* TerrainUploadManager::upload_slice (terrain_upload.rs:84-275) -> vkCmdCopyBufferToImage with an
  * offset (command_buffer.rs:262-298): replace one 16-thick slab of the region.  axis 0/1/2 = x/y/z;
  * texel_offset (multiple of 16, < 256) is the slab's start along that axis; the data is a dense box of
- * extent (16,R,R) / (R,16,R) / (R,R,16), x fastest (terrain_upload.rs:96-100). */
+ * extent (16,R,R) / (R,16,R) / (R,R,16), x fastest (terrain_upload.rs:96-100).  Only the slab is re-tiled on the device (one
+ * launch over its 16 R^2 voxels + the nibble-map words it touches); any region size. */
 int rt_upload_slice(RtContext* ctx, int axis, int texel_offset,
                     const uint32_t* materials, const uint8_t* minefield);
 
@@ -227,7 +230,8 @@ size_t rt_buffer_bytes(RtContext* ctx, int buffer_id);
  * the images bound at descriptor_sets.rs:64-84. NULL on bad id. */
 void* rt_device_ptr(RtContext* ctx, int buffer_id);
 
-/* Run on a caller-provided hipStream_t (NULL = the context's own stream). */
+/* Run on a caller-provided hipStream_t.  NULL = the context's own non-blocking stream (NOT the legacy null stream: work on
+ * the null stream is not ordered against the context's frames). */
 int rt_set_stream(RtContext* ctx, void* hip_stream);
 
 /* Multi-GPU tile split: number of 8x8 tiles this context renders, and the padded
@@ -242,7 +246,8 @@ int rt_untile(RtContext* ctx, int buffer_id, const void* gathered_dev, int world
 /* The six reference-format planes (ids 0..5) of a context are one contiguous device block (each plane padded to 256 B),
  * so a multi-GPU host gathers a frame with ONE collective: rt_gbuffer_ptr/bytes give the block, rt_gbuffer_offset the
  * start of plane `id` inside it.  rt_untile_gbuffer scatters `world` gathered blocks (rank-major, device memory) into six
- * row-major full-frame planes frames_dev[0..5] (device pointers; NULL entries are skipped). */
+ * row-major full-frame planes frames_dev[0..5] (device pointers; NULL entries are skipped).  `world` must be the
+ * context's own tile_world (>= 2): the block layout is the context's. */
 void*  rt_gbuffer_ptr(RtContext* ctx);
 size_t rt_gbuffer_bytes(RtContext* ctx);
 size_t rt_gbuffer_offset(RtContext* ctx, int buffer_id);
@@ -258,6 +263,30 @@ int rt_denoise(RtContext* ctx, int faithful);
 /* finalize.comp (pipeline.rs:117-123): albedo*light*16 + emission*4, distance fog, tone curve, blue-noise dither, Y flip
  * -> RT_BUF_FINAL_BGRA8.  Whole-frame contexts only. Asynchronous. */
 int rt_finalize(RtContext* ctx);
+
+/* Multi-GPU frame assembly behind the boundary (the reference is single-GPU, this replaces nothing of it): every
+ * rank renders the tiles t % tile_world == tile_rank of the frame (RtConfig) and calls rt_gather_gbuffer on its context: the
+ * six reference-format planes of every rank travel to `root` over RCCL (grouped ncclSend/ncclRecv on the context's stream, so
+ * the transfer is ordered after the frame's kernels without any host synchronisation) and the root scatters them into the six
+ * row-major full-frame device planes frames_dev[0..5] (NULL entries are skipped; ignored on the other ranks; a NULL array
+ * selects planes the library owns, see rt_frame_ptr).  With
+ * overlapped != 0 the transfer and the un-tiling run on a second stream from a staging copy, so the caller may draw the next
+ * frame at once; rt_sync waits for both streams.  tile_world == 1: plain copies.  `comm` is an ncclComm_t over the tile_world
+ * ranks in tile_rank order — from the host's own RCCL, or from the helpers below (librccl is loaded on first use only):
+ *   rt_comm_unique_id   ncclGetUniqueId into a 128-byte buffer (one rank; the host distributes it)
+ *   rt_comm_init_rank   ncclCommInitRank(tile_world, id, tile_rank) on the context's device (one process per GPU)
+ *   rt_comm_init_all    ncclCommInitAll for one process that drives ndev devices (rt_bench --gpus N)
+ *   rt_comm_destroy     ncclCommDestroy */
+int rt_comm_unique_id(void* id_out, size_t bytes);
+int rt_comm_init_rank(RtContext* ctx, const void* id, size_t bytes, void** comm_out);
+int rt_comm_init_all(int ndev, const int* devices, void** comms_out);
+int rt_comm_destroy(void* comm);
+int rt_gather_gbuffer(RtContext* ctx, void* comm, int root, void* const* frames_dev, int overlapped);
+/* frames_dev == NULL on the root: the frame is assembled in planes the library owns (W x H, reference formats, row-major),
+ * so a host needs no device allocator of its own: rt_frame_ptr returns plane `id` (0..5; NULL before the first such gather)
+ * for rt_denoise_planes / rt_finalize_planes, rt_frame_readback copies it to host memory after waiting for the gather. */
+void* rt_frame_ptr(RtContext* ctx, int buffer_id);
+int rt_frame_readback(RtContext* ctx, int buffer_id, void* dst, size_t bytes);
 
 /* The same two passes on caller-owned row-major device planes of cfg.width x cfg.height pixels in the reference formats
  * (e.g. the frame rt_untile_gbuffer assembled on rank 0 from the ranks' tiles): rt_denoise_planes filters `lighting_rgba16`

@@ -41,7 +41,8 @@ class RtOracleHit(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        # RT_ORACLE_LIB: load another build of the same source (the sanitizer build of `make -C oracle asan`)
+        _LIB = C.CDLL(os.environ.get("RT_ORACLE_LIB") or build())
         _LIB.rt_oracle_render.restype = C.c_int
         _LIB.rt_oracle_pixel_of.restype = C.c_uint32
         _LIB.rt_oracle_pixel_of.argtypes = [C.c_uint32, C.c_uint32]

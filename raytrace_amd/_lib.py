@@ -16,6 +16,8 @@ ABI_SYMBOLS = (
     "rt_tile_count", "rt_tile_capacity", "rt_untile", "rt_gbuffer_ptr", "rt_gbuffer_bytes", "rt_gbuffer_offset",
     "rt_untile_gbuffer", "rt_denoise", "rt_finalize", "rt_denoise_planes", "rt_finalize_planes", "rt_kernel_in_use", "rt_get_counters", "rt_reset_counters", "rt_get_timing",
     "rt_abi_version",
+    "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_gather_gbuffer", "rt_frame_ptr",
+    "rt_frame_readback",
 )
 
 _amd = None
@@ -74,6 +76,17 @@ def amd():
         lib.rt_reset_counters.argtypes = [P]
         lib.rt_get_timing.argtypes = [P, C.POINTER(RtTiming)]
         lib.rt_abi_version.restype = C.c_uint32
+        lib.rt_comm_unique_id.argtypes = [P, C.c_size_t]
+        lib.rt_comm_init_rank.argtypes = [P, P, C.c_size_t, C.POINTER(P)]
+        lib.rt_comm_init_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(P)]
+        lib.rt_comm_destroy.argtypes = [P]
+        lib.rt_gather_gbuffer.argtypes = [P, P, C.c_int, P, C.c_int]
+        lib.rt_frame_ptr.argtypes = [P, C.c_int]
+        lib.rt_frame_ptr.restype = P
+        lib.rt_frame_readback.argtypes = [P, C.c_int, P, C.c_size_t]
+        lib.rt_frame_readback.restype = C.c_int
+        for name in ("rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_gather_gbuffer"):
+            getattr(lib, name).restype = C.c_int
         for name in ("rt_upload_world", "rt_upload_slice", "rt_upload_noise", "rt_draw_frame", "rt_sync", "rt_readback",
                      "rt_set_stream", "rt_tile_count", "rt_tile_capacity", "rt_untile", "rt_untile_gbuffer", "rt_denoise", "rt_finalize",
                      "rt_denoise_planes", "rt_finalize_planes", "rt_get_counters",
@@ -90,7 +103,8 @@ def host():
         amd()  # dependency; also enforces the loud failure
         if not os.path.exists(LIB_HOST_PATH):
             raise NativeLibraryMissing("%s not found (run `python -m raytrace_amd.build`)" % LIB_HOST_PATH)
-        lib = C.CDLL(LIB_HOST_PATH)
+        # RT_HOST_LIB: another build of the same sources (the CPU sanitizer build, `make -C oracle asan`)
+        lib = C.CDLL(os.environ.get("RT_HOST_LIB") or LIB_HOST_PATH)
         P = C.c_void_p
         lib.rth_material_pack.argtypes = [C.c_int]
         lib.rth_material_pack.restype = C.c_uint32
@@ -117,6 +131,8 @@ def host():
         lib.rth_chunk_storage_stats.argtypes = [P, P, P]
         lib.rth_tum_new.argtypes = [C.c_uint64]
         lib.rth_tum_new.restype = P
+        lib.rth_tum_new_r.argtypes = [C.c_uint64, C.c_int]
+        lib.rth_tum_new_r.restype = P
         lib.rth_tum_free.argtypes = [P]
         lib.rth_tum_free.restype = None
         lib.rth_tum_request.argtypes = [P, C.c_int, C.c_int]
@@ -139,6 +155,7 @@ def host():
         lib.rth_game_get_sun_angle.restype = C.c_float
         lib.rth_game_set_world.argtypes = [P, P, P]
         lib.rth_game_generate_world.argtypes = [P, C.c_uint64]
+        lib.rth_game_generate_world_r.argtypes = [P, C.c_uint64, C.c_int]
         lib.rth_create_instance.argtypes = [C.POINTER(RtConfig), P, P, P, C.c_size_t]
         lib.rth_create_instance.restype = P
         lib.rth_pipeline_free.argtypes = [P]

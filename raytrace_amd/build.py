@@ -66,7 +66,7 @@ def build(force=False, verbose=True):
              ["-L", HERE, "-lrt_amd", "-ldl", "-Wl,-rpath,$ORIGIN"])
         built.append(LIB_HOST)
     if all(os.path.exists(s) for s in BENCH_SRCS) and (force or _stale(BENCH, BENCH_SRCS + [LIB_HOST, LIB_AMD])):
-        _run([CXX] + CXX_FLAGS + ["-o", BENCH] + BENCH_SRCS + ["-L", HERE, "-lrt_host", "-lrt_amd", "-Wl,-rpath,$ORIGIN"])
+        _run([CXX] + CXX_FLAGS + ["-o", BENCH] + BENCH_SRCS + ["-L", HERE, "-lrt_host", "-lrt_amd", "-lpthread", "-Wl,-rpath,$ORIGIN"])
         built.append(BENCH)
     return built
 

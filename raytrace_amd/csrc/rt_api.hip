@@ -4,9 +4,13 @@
 // device is missing, rt_create fails with RT_ERR_NO_DEVICE and the caller gets no context.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen'ed on first use (rt_comm_* / rt_gather_gbuffer)
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -36,11 +40,14 @@ struct RtContext {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err = "";
     bool has_world = false, has_noise = false;
+    bool world_resident = false;          // a full region has been uploaded once (slabs may patch it)
+    int bad_slab_axis = -1, bad_slab_offset = -1;   // a rejected slab sits in the region: not drawable until that slab is replaced
 
     // scene
     uint8_t* d_mine_lin = nullptr; uint32_t* d_mat_lin = nullptr;
     uint8_t* d_mine_sw = nullptr; uint32_t* d_mat_sw = nullptr;
     uint32_t* d_coarse = nullptr; uint32_t* d_noise = nullptr; uint32_t* d_flag = nullptr;
+    uint8_t* d_slab_mine = nullptr; uint32_t* d_slab_mat = nullptr;   // rt_upload_slice staging: one 16-thick slab
 
     // tiling
     int tiles_x = 0, tiles_y = 0, ntiles_total = 0, ntiles_local = 0, tile_capacity = 0;
@@ -96,8 +103,21 @@ struct RtContext {
     bool frame_recorded = false;
     uint64_t rays_bound = 0;
 
+    // multi-GPU gather (rt_gather_gbuffer): root's staging for the ranks' blocks; the overlapped mode's second stream,
+    // two send-side staging copies of this rank's block and the events that order them
+    void* frame_planes[6] = {};   // root, frames_dev == NULL: the library's own row-major full-frame planes (rt_frame_ptr)
+    uint8_t* gathered[2] = {nullptr, nullptr};
+    uint8_t* stage[2] = {nullptr, nullptr};
+    hipStream_t gather_stream = nullptr;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    bool ev_free_recorded[2] = {false, false};
+    uint64_t gathers = 0;
+    uint32_t timer_overflow = 0;   // launches that found the event pool full (RT_FLAG_TIMING without rt_get_timing)
+
     std::vector<void*> allocs;
 };
+
+constexpr size_t kMaxTimerEvents = 2 * 4096;   // LaunchTimer pool cap: pairs beyond it are not timed (counted in timer_overflow)
 
 namespace {
 
@@ -185,6 +205,7 @@ struct LaunchTimer {
     LaunchTimer(RtContext* ctx, int kind)
         : c(ctx), on(kind == 0 ? (ctx->cfg.flags & RT_FLAG_TIMING) != 0 : (ctx->cfg.flags & RT_FLAG_TIMING_ALL) == RT_FLAG_TIMING_ALL), idx(0) {
         if (!on) return;
+        if (c->ev_used + 2 > kMaxTimerEvents) { c->timer_overflow++; on = false; return; }
         if (c->ev_used + 2 > c->ev_pool.size()) {
             for (int k = 0; k < 2; k++) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } c->ev_pool.push_back(e); }
         }
@@ -373,7 +394,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
             uint64_t np = c->npix_pad ? c->npix_pad : 1;
             uint64_t B = (2ull << 30) / (16ull * np);
             if (B > (1ull << 30) / np) B = (1ull << 30) / np;
-            if (const char* s = getenv("RT_PERSIST_BATCH")) { long long v = atoll(s); if (v > 0) B = (uint64_t)v; }
+            if (const char* s = getenv("RT_PERSIST_BATCH")) { long long v = atoll(s); if (v > 0 && (uint64_t)v < B) B = (uint64_t)v; }   // may only lower the bound
             if (B < 1) B = 1;
             if (B > (uint64_t)cfg->spp) B = (uint64_t)cfg->spp;
             c->persist_batch = (uint32_t)B;
@@ -422,6 +443,8 @@ void rt_destroy(RtContext* ctx) {
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ev_frame0) (void)hipEventDestroy(ctx->ev_frame0);
     if (ctx->ev_frame1) (void)hipEventDestroy(ctx->ev_frame1);
+    if (ctx->gather_stream) { (void)hipStreamSynchronize(ctx->gather_stream); (void)hipStreamDestroy(ctx->gather_stream); }
+    for (int i = 0; i < 2; i++) { if (ctx->ev_ready[i]) (void)hipEventDestroy(ctx->ev_ready[i]); if (ctx->ev_free[i]) (void)hipEventDestroy(ctx->ev_free[i]); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -430,6 +453,8 @@ int rt_set_stream(RtContext* ctx, void* hip_stream) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // NULL selects the context's own (non-blocking) stream, NOT the legacy null stream: work a caller enqueues on the null
+    // stream is not ordered against the context's frames — pass an explicit stream handle to share one
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return RT_OK;
 }
@@ -442,9 +467,12 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
     RT_HIP(ctx, hipMemcpy(ctx->d_mat_lin, materials, ctx->vox * sizeof(uint32_t), hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_mine_lin, minefield, ctx->vox, hipMemcpyHostToDevice));
     ctx->has_world = false;
+    ctx->world_resident = false;
     int rc = reflatten(ctx);
     if (rc != RT_OK) return rc;
     ctx->has_world = true;
+    ctx->world_resident = true;
+    ctx->bad_slab_axis = ctx->bad_slab_offset = -1;
     return RT_OK;
 }
 
@@ -454,23 +482,38 @@ int rt_upload_slice(RtContext* ctx, int axis, int texel_offset, const uint32_t* 
     const size_t kR = (size_t)ctx->region;
     if (axis < 0 || axis > 2 || texel_offset < 0 || texel_offset + RT_SLICE_SIZE > ctx->region || texel_offset % RT_SLICE_SIZE != 0)
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_slice: bad axis or offset");
-    if (!ctx->has_world) return fail(ctx, RT_ERR_NOT_READY, "rt_upload_slice: upload the full region first");
+    if (!ctx->world_resident) return fail(ctx, RT_ERR_NOT_READY, "rt_upload_slice: upload the full region first");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t S = RT_SLICE_SIZE;
-    auto copy = [&](void* dst, const void* src, size_t elem) -> hipError_t {
-        char* d = (char*)dst;
-        if (axis == 2) return hipMemcpy(d + (size_t)texel_offset * kR * kR * elem, src, S * kR * kR * elem, hipMemcpyHostToDevice);
-        if (axis == 1)  // rows = z, each 16*R contiguous elements
-            return hipMemcpy2D(d + (size_t)texel_offset * kR * elem, (size_t)kR * kR * elem, src, S * kR * elem, S * kR * elem, kR,
-                               hipMemcpyHostToDevice);
-        // axis 0: rows = (z,y), each 16 contiguous elements
-        return hipMemcpy2D(d + (size_t)texel_offset * elem, (size_t)kR * elem, src, S * elem, S * elem, (size_t)kR * kR,
-                           hipMemcpyHostToDevice);
-    };
-    RT_HIP(ctx, copy(ctx->d_mat_lin, materials, sizeof(uint32_t)));
-    RT_HIP(ctx, copy(ctx->d_mine_lin, minefield, 1));
-    return reflatten(ctx);
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));          // frames in flight still read the region
+    // Incremental: the slab goes to a staging buffer (5 bytes x 16 x R^2), ONE launch re-tiles just its 16 R^2 voxels into the
+    // brick-swizzled arrays and a second rebuilds the nibble-map words it touches (<= 4 x 64^2 entries) — not the whole
+    // region (the full re-flatten moved 80 MiB for a 5 MiB slab).
+    const size_t n = (size_t)RT_SLICE_SIZE * kR * kR;
+    if (!ctx->d_slab_mat) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mat, n));
+    if (!ctx->d_slab_mine) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mine, n));
+    // from here on the resident copy is being modified: a failure leaves no drawable world (as in rt_upload_world)
+    ctx->has_world = false;
+    RT_HIP(ctx, hipMemcpy(ctx->d_slab_mat, materials, n * sizeof(uint32_t), hipMemcpyHostToDevice));   // blocking: the host
+    RT_HIP(ctx, hipMemcpy(ctx->d_slab_mine, minefield, n, hipMemcpyHostToDevice));                      // buffers are borrowed
+    const bool validate = (ctx->cfg.flags & RT_FLAG_TRUSTED_WORLD) == 0;
+    if (validate) RT_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(uint32_t), ctx->stream));
+    {
+        LaunchTimer t(ctx, 1);
+        RT_HIP(ctx, rtd::launch_flatten_slab(ctx->d_slab_mine, ctx->d_slab_mat, ctx->d_mine_sw, ctx->d_mat_sw, ctx->d_coarse, ctx->d_flag,
+                                             ctx->logr, axis, texel_offset, ctx->stream));
+    }
+    if (validate) {   // values above 30 are rejected like in rt_upload_world; a host that vouches for its data skips the round trip
+        uint32_t flag = 0;
+        RT_HIP(ctx, hipMemcpyAsync(&flag, ctx->d_flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (flag) {   // the slab is in the region already: nothing is drawn until this very slab is replaced (or the region re-uploaded)
+            ctx->bad_slab_axis = axis; ctx->bad_slab_offset = texel_offset;
+            return fail(ctx, RT_ERR_INVALID_ARG, "minefield slab holds a value above 30 (the reference writes 0..6, src/world/chunk.rs:163-183)");
+        }
+    }
+    if (ctx->bad_slab_axis == axis && ctx->bad_slab_offset == texel_offset) ctx->bad_slab_axis = ctx->bad_slab_offset = -1;
+    ctx->has_world = ctx->bad_slab_axis < 0;
+    return RT_OK;
 }
 
 int rt_upload_noise(RtContext* ctx, const uint8_t* rgba8) {
@@ -556,6 +599,7 @@ int rt_sync(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->gather_stream) RT_HIP(ctx, hipStreamSynchronize(ctx->gather_stream));
     return RT_OK;
 }
 
@@ -654,14 +698,180 @@ int rt_untile_gbuffer(RtContext* ctx, const void* gathered_dev, int world, void*
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (!gathered_dev || !frames_dev || world < 1) return fail(ctx, RT_ERR_INVALID_ARG, "rt_untile_gbuffer: bad argument");
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    // the per-rank block layout (plane offsets, block size) is this context's own: only valid for its own split
+    if (world != ctx->cfg.tile_world || world < 2)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_untile_gbuffer: world must equal the context's tile_world (>= 2)");
     const int capacity = (ctx->ntiles_total + world - 1) / world;
-    if (world == ctx->cfg.tile_world && capacity != ctx->tile_capacity) return fail(ctx, RT_ERR_INVALID_ARG, "rt_untile_gbuffer: capacity mismatch");
     for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++) {
         if (!frames_dev[b]) continue;
         RT_HIP(ctx, rtd::launch_untile_strided((const uint8_t*)gathered_dev + ctx->gbuffer_offset[b], ctx->gbuffer_bytes, frames_dev[b], world,
                                                capacity, ctx->tiles_x, ctx->tiles_y, ctx->cfg.width, ctx->cfg.height,
                                                (int)kBytesPerPixel[b], ctx->stream));
     }
+    return RT_OK;
+}
+
+
+// ---- multi-GPU: RCCL gather of the tile-split G-buffer ------------------------------------------------------
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+// librccl is 0.5 GB: loaded on first use only.  A copy the process already holds (e.g. the one PyTorch ships) is reused,
+// so a communicator created by the host's own RCCL stays valid here.
+bool rccl_load() {
+    std::call_once(g_rccl_once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names) { if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD); }
+        for (const char* n : names) { if (!g_rccl.handle) g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
+        if (!g_rccl.handle) { g_rccl.error = std::string("cannot load librccl: ") + dlerror(); return; }
+#define RT_RCCL_SYM(name) g_rccl.name = (decltype(g_rccl.name))dlsym(g_rccl.handle, "nccl" #name); if (!g_rccl.name) g_rccl.error = "librccl lacks nccl" #name;
+        RT_RCCL_SYM(GetUniqueId) RT_RCCL_SYM(CommInitRank) RT_RCCL_SYM(CommInitAll) RT_RCCL_SYM(CommDestroy) RT_RCCL_SYM(GroupStart)
+        RT_RCCL_SYM(GroupEnd) RT_RCCL_SYM(Send) RT_RCCL_SYM(Recv) RT_RCCL_SYM(GetErrorString)
+#undef RT_RCCL_SYM
+    });
+    return g_rccl.error.empty();
+}
+#define RT_NCCL(ctx, call)                                                                                   \
+    do { ncclResult_t r_ = (call); if (r_ != ncclSuccess)                                                    \
+        return fail(ctx, RT_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } while (0)
+}  // namespace
+
+int rt_comm_unique_id(void* id_out, size_t bytes) {
+    if (!id_out || bytes != NCCL_UNIQUE_ID_BYTES) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_comm_unique_id: need a 128-byte buffer");
+    if (!rccl_load()) return fail(nullptr, RT_ERR_UNIMPLEMENTED, g_rccl.error);
+    ncclUniqueId id;
+    RT_NCCL(nullptr, g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return RT_OK;
+}
+
+int rt_comm_init_rank(RtContext* ctx, const void* id, size_t bytes, void** comm_out) {
+    if (comm_out) *comm_out = nullptr;
+    if (!ctx || !id || bytes != NCCL_UNIQUE_ID_BYTES || !comm_out) return fail(ctx, RT_ERR_INVALID_ARG, "rt_comm_init_rank: bad argument");
+    if (!rccl_load()) return fail(ctx, RT_ERR_UNIMPLEMENTED, g_rccl.error);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    RT_NCCL(ctx, g_rccl.CommInitRank(&comm, ctx->cfg.tile_world, uid, ctx->cfg.tile_rank));
+    *comm_out = comm;
+    return RT_OK;
+}
+
+int rt_comm_init_all(int ndev, const int* devices, void** comms_out) {
+    if (ndev < 1 || !comms_out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_comm_init_all: bad argument");
+    if (!rccl_load()) return fail(nullptr, RT_ERR_UNIMPLEMENTED, g_rccl.error);
+    std::vector<ncclComm_t> comms((size_t)ndev, nullptr);
+    RT_NCCL(nullptr, g_rccl.CommInitAll(comms.data(), ndev, devices));
+    for (int i = 0; i < ndev; i++) comms_out[i] = comms[(size_t)i];
+    return RT_OK;
+}
+
+int rt_comm_destroy(void* comm) {
+    if (!comm) return RT_OK;
+    if (!rccl_load()) return fail(nullptr, RT_ERR_UNIMPLEMENTED, g_rccl.error);
+    RT_NCCL(nullptr, g_rccl.CommDestroy((ncclComm_t)comm));
+    return RT_OK;
+}
+
+int rt_gather_gbuffer(RtContext* ctx, void* comm_, int root, void* const* frames_dev, int overlapped) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    const int world = ctx->cfg.tile_world, rank = ctx->cfg.tile_rank;
+    if (root < 0 || root >= world) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_gbuffer: root out of range");
+    if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_gather_gbuffer: no frame drawn yet");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (rank == root && !frames_dev) {
+        // no caller-owned planes: assemble into the library's own (allocated once; rt_frame_ptr / rt_frame_readback)
+        for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++)
+            if (!ctx->frame_planes[b]) {
+                uint8_t* p = nullptr;
+                RT_HIP(ctx, dev_alloc(ctx, &p, (size_t)ctx->cfg.width * ctx->cfg.height * kBytesPerPixel[b]));
+                ctx->frame_planes[b] = p;
+            }
+        frames_dev = ctx->frame_planes;
+    }
+    if (world == 1 && !comm_) {
+        // one context holds the whole frame, row-major already: plain copies on the context's stream
+        for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++)
+            if (frames_dev[b]) RT_HIP(ctx, hipMemcpyAsync(frames_dev[b], ctx->planes[b], ctx->plane_pixels * kBytesPerPixel[b], hipMemcpyDeviceToDevice, ctx->stream));
+        return RT_OK;
+    }
+    if (!comm_) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_gbuffer: null communicator");
+    if (!rccl_load()) return fail(ctx, RT_ERR_UNIMPLEMENTED, g_rccl.error);
+    ncclComm_t comm = (ncclComm_t)comm_;
+    const size_t gb = ctx->gbuffer_bytes;
+    const int s = overlapped ? (int)(ctx->gathers & 1u) : 0;
+    if (rank == root && !ctx->gathered[s]) RT_HIP(ctx, dev_alloc(ctx, &ctx->gathered[s], gb * (size_t)world));
+    hipStream_t gs = ctx->stream;
+    const uint8_t* src = (const uint8_t*)ctx->gbuffer;
+    if (overlapped) {
+        // The frame's block is copied to one of two staging buffers on the render stream (so the next frame may overwrite the
+        // planes), everything else runs on a second stream: frame k's send/recv + un-tile overlap frame k+1's kernels.
+        if (!ctx->gather_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->gather_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            if (!ctx->ev_ready[i]) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ready[i], hipEventDisableTiming));
+            if (!ctx->ev_free[i]) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming));
+        }
+        if (!ctx->stage[s]) RT_HIP(ctx, dev_alloc(ctx, &ctx->stage[s], gb));
+        if (ctx->ev_free_recorded[s]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_free[s], 0));   // gather k-2 has left stage[s]
+        RT_HIP(ctx, hipMemcpyAsync(ctx->stage[s], ctx->gbuffer, gb, hipMemcpyDeviceToDevice, ctx->stream));
+        RT_HIP(ctx, hipEventRecord(ctx->ev_ready[s], ctx->stream));
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->gather_stream, ctx->ev_ready[s], 0));
+        gs = ctx->gather_stream;
+        src = ctx->stage[s];
+    }
+    // every rank sends its block to the root; the root posts one receive per rank (its own block included).  Each peer uses
+    // its own xGMI link into the root, so the transfers run in parallel.
+    RT_NCCL(ctx, g_rccl.GroupStart());
+    if (rank == root)
+        for (int r = 0; r < world; r++) RT_NCCL(ctx, g_rccl.Recv(ctx->gathered[s] + (size_t)r * gb, gb, ncclUint8, r, comm, gs));
+    RT_NCCL(ctx, g_rccl.Send(src, gb, ncclUint8, root, comm, gs));
+    RT_NCCL(ctx, g_rccl.GroupEnd());
+    if (rank == root) {
+        const int capacity = (ctx->ntiles_total + world - 1) / world;
+        for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++) {
+            if (!frames_dev[b]) continue;
+            if (world == 1) {   // a one-rank communicator (the transfer went to itself): the block holds row-major planes
+                RT_HIP(ctx, hipMemcpyAsync(frames_dev[b], ctx->gathered[s] + ctx->gbuffer_offset[b], ctx->plane_pixels * kBytesPerPixel[b],
+                                           hipMemcpyDeviceToDevice, gs));
+                continue;
+            }
+            RT_HIP(ctx, rtd::launch_untile_strided(ctx->gathered[s] + ctx->gbuffer_offset[b], gb, frames_dev[b], world, capacity, ctx->tiles_x,
+                                                   ctx->tiles_y, ctx->cfg.width, ctx->cfg.height, (int)kBytesPerPixel[b], gs));
+        }
+    }
+    if (overlapped) { RT_HIP(ctx, hipEventRecord(ctx->ev_free[s], gs)); ctx->ev_free_recorded[s] = true; }
+    ctx->gathers++;
+    return RT_OK;
+}
+
+void* rt_frame_ptr(RtContext* ctx, int id) {
+    if (!ctx || id < 0 || id > RT_BUF_FOG_RGBA8) return nullptr;
+    return ctx->frame_planes[id];
+}
+
+int rt_frame_readback(RtContext* ctx, int id, void* dst, size_t bytes) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (id < 0 || id > RT_BUF_FOG_RGBA8 || !dst) return fail(ctx, RT_ERR_INVALID_ARG, "rt_frame_readback: bad buffer id or null destination");
+    if (!ctx->frame_planes[id]) return fail(ctx, RT_ERR_NOT_READY, "rt_frame_readback: no frame assembled by rt_gather_gbuffer(frames_dev = NULL) yet");
+    if (bytes != (size_t)ctx->cfg.width * ctx->cfg.height * kBytesPerPixel[id]) return fail(ctx, RT_ERR_INVALID_ARG, "rt_frame_readback: size mismatch");
+    int rc = rt_sync(ctx);
+    if (rc != RT_OK) return rc;
+    RT_HIP(ctx, hipMemcpy(dst, ctx->frame_planes[id], bytes, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

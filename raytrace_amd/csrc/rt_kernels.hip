@@ -39,10 +39,47 @@ __global__ __launch_bounds__(256) void k_flatten_voxels(const uint8_t* __restric
     mat_sw[i] = mat_lin[src];
 }
 
+// rt_upload_slice: the same re-tiling for ONE 16-thick slab (TerrainUploadManager::upload_slice, terrain_upload.rs:84-275 ->
+// vkCmdCopyBufferToImage with an offset).  The slab arrives as a dense box of extent 16 along `axis` and R along the other
+// two (x fastest); thread i handles swizzled voxel i of the slab's bricks — 4 brick layers along `axis`, whole bricks, so every
+// thread writes inside one 64-byte line run.  Values above kMaxStepValue raise the flag as in the full upload.
+__global__ __launch_bounds__(256) void k_flatten_slab(const uint8_t* __restrict__ mine_slab, const uint32_t* __restrict__ mat_slab,
+                                                      uint8_t* __restrict__ mine_sw, uint32_t* __restrict__ mat_sw,
+                                                      uint32_t* __restrict__ bad_value_flag, int logr, int axis, int offset) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly 16 * R^2
+    const int lb = logr - 2;
+    const uint32_t bmask = (1u << lb) - 1u;
+    const uint32_t l = i & 63u, sb = i >> 6;              // sb: brick within the slab, 4 layers along `axis`
+    // brick coordinates: the two full axes take lb bits each, the slab axis 2 bits (layer) on top of offset/4
+    uint32_t bc[3];
+    uint32_t rest = sb;
+    for (int a = 0; a < 3; a++) {
+        if (a == axis) { bc[a] = (uint32_t)(offset >> 2) + (rest & 3u); rest >>= 2; }
+        else { bc[a] = rest & bmask; rest >>= lb; }
+    }
+    const uint32_t ix = (bc[0] << 2) | (l & 3u), iy = (bc[1] << 2) | ((l >> 2) & 3u), iz = (bc[2] << 2) | (l >> 4);
+    const uint32_t R = 1u << logr;
+    const uint32_t sx = axis == 0 ? ix - (uint32_t)offset : ix, sy = axis == 1 ? iy - (uint32_t)offset : iy,
+                   sz = axis == 2 ? iz - (uint32_t)offset : iz;
+    const uint32_t ex = axis == 0 ? (uint32_t)RT_SLICE_SIZE : R, ey = axis == 1 ? (uint32_t)RT_SLICE_SIZE : R;
+    const size_t src = ((size_t)sz * ey + sy) * ex + sx;
+    const size_t dst = ((((size_t)bc[2] << lb) + bc[1]) << lb) + bc[0];
+    const uint8_t v = mine_slab[src];
+    if (v > kMaxStepValue) atomicOr(bad_value_flag, 1u);
+    mine_sw[(dst << 6) | l] = v;
+    mat_sw[(dst << 6) | l] = mat_slab[src];
+}
+
 // One thread per nibble-map word = 8 consecutive coarse cubes (x-adjacent).  A coarse cube has edge R/64 and is made of
 // (R/256)^3 4^3-bricks of 64 contiguous bytes each in the swizzled minefield.
-__global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict__ mine_sw, uint32_t* __restrict__ coarse, int logr) {
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly kCoarseWords
+// (word0, nwords[3]): the box of words to rebuild — the whole map for an upload, the layers a slab touches for rt_upload_slice.
+__global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict__ mine_sw, uint32_t* __restrict__ coarse, int logr,
+                                                      uint3 word0, uint3 nwords) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= nwords.x * nwords.y * nwords.z) return;
+    // word (wx, cy, cz): wx in [0, 8) covers coarse cubes cx = 8 wx .. 8 wx + 7
+    const uint32_t wx = word0.x + t % nwords.x, cy_ = word0.y + (t / nwords.x) % nwords.y, cz_ = word0.z + t / (nwords.x * nwords.y);
+    const uint32_t w = (cz_ << 9) | (cy_ << 3) | wx;
     const int lb = logr - 2, sub = logr - 8;               // sub: log2(4^3-bricks per coarse cube edge)
     const uint32_t nsub = 1u << sub;
     uint32_t word = 0;
@@ -487,7 +524,26 @@ hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint
                           uint32_t* coarse, uint32_t* bad_flag, int logr, hipStream_t st) {
     hipLaunchKernelGGL(k_flatten_voxels, dim3((1u << (3 * logr)) / 256u), dim3(256), 0, st, mine_lin, mat_lin, mine_sw, mat_sw,
                        bad_flag, logr);
-    hipLaunchKernelGGL(k_build_coarse, dim3(kCoarseWords / 256), dim3(256), 0, st, mine_sw, coarse, logr);
+    hipLaunchKernelGGL(k_build_coarse, dim3(kCoarseWords / 256), dim3(256), 0, st, mine_sw, coarse, logr, make_uint3(0, 0, 0),
+                       make_uint3(8, 64, 64));
+    return hipGetLastError();
+}
+
+hipError_t launch_flatten_slab(const uint8_t* mine_slab, const uint32_t* mat_slab, uint8_t* mine_sw, uint32_t* mat_sw, uint32_t* coarse,
+                               uint32_t* bad_flag, int logr, int axis, int offset, hipStream_t st) {
+    const uint32_t R = 1u << logr;
+    hipLaunchKernelGGL(k_flatten_slab, dim3(RT_SLICE_SIZE * R * R / 256u), dim3(256), 0, st, mine_slab, mat_slab, mine_sw, mat_sw, bad_flag,
+                       logr, axis, offset);
+    // nibble-map entries the slab touches: coarse cubes have edge R/64, so 16 voxels are 1024/R layers (4, 2, 1) — rounded out
+    // to whole words along x (a word holds 8 x-adjacent cubes, all recomputed from the re-tiled bytes)
+    const uint32_t e = R / 64u;
+    const uint32_t c0 = (uint32_t)offset / e, c1 = ((uint32_t)offset + RT_SLICE_SIZE - 1u) / e;   // inclusive cube range along `axis`
+    uint3 w0 = make_uint3(0, 0, 0), nw = make_uint3(8, 64, 64);
+    if (axis == 0) { w0.x = c0 / 8u; nw.x = c1 / 8u - w0.x + 1u; }
+    else if (axis == 1) { w0.y = c0; nw.y = c1 - c0 + 1u; }
+    else { w0.z = c0; nw.z = c1 - c0 + 1u; }
+    const uint32_t n = nw.x * nw.y * nw.z;
+    hipLaunchKernelGGL(k_build_coarse, dim3((n + 255u) / 256u), dim3(256), 0, st, mine_sw, coarse, logr, w0, nw);
     return hipGetLastError();
 }
 

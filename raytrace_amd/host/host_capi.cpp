@@ -132,11 +132,16 @@ struct HostTum {
     world::ChunkStorage chunks;
     std::vector<uint32_t> materials;
     std::vector<uint8_t> minefield;
-    HostTum(uint64_t seed) : chunks("", seed), materials(world::kRegionVolume), minefield(world::kRegionVolume) {
-        world::assemble_region_procedural(seed, materials.data(), minefield.data());
+    int region;
+    HostTum(uint64_t seed, int r) : tum(r), chunks("", seed), materials((size_t)r * r * r), minefield((size_t)r * r * r), region(r) {
+        world::assemble_region_procedural(seed, materials.data(), minefield.data(), r);
     }
 };
-void* rth_tum_new(uint64_t seed) { return new (std::nothrow) HostTum(seed); }
+void* rth_tum_new(uint64_t seed) { return new (std::nothrow) HostTum(seed, world::kRegion); }
+void* rth_tum_new_r(uint64_t seed, int region) {
+    if (region != 256 && region != 512 && region != 1024) return nullptr;
+    return new (std::nothrow) HostTum(seed, region);
+}
 void rth_tum_free(void* t) { delete static_cast<HostTum*>(t); }
 void rth_tum_request(void* t, int axis, int increase) {
     auto* h = static_cast<HostTum*>(t);
@@ -148,7 +153,7 @@ int rth_tum_pending(void* t) { return (int)static_cast<HostTum*>(t)->tum.pending
 int rth_tum_step(void* t) {
     auto* h = static_cast<HostTum*>(t);
     return h->tum.setup_next_request(h->chunks, [h](int axis, int off, const uint32_t* m, const uint8_t* f) {
-        const int R = world::kRegion, S = RT_SLICE_SIZE;
+        const int R = h->region, S = RT_SLICE_SIZE;
         world::Dims3 shape{R, R, R};
         (axis == 0 ? shape.x : (axis == 1 ? shape.y : shape.z)) = S;
         world::Dims3 at{0, 0, 0};
@@ -161,8 +166,8 @@ int rth_tum_step(void* t) {
 void rth_tum_render_offset(void* t, long* out3) { static_cast<HostTum*>(t)->tum.get_render_offset(out3); }
 void rth_tum_region(void* t, uint32_t* materials, uint8_t* minefield) {
     auto* h = static_cast<HostTum*>(t);
-    std::memcpy(materials, h->materials.data(), sizeof(uint32_t) * world::kRegionVolume);
-    std::memcpy(minefield, h->minefield.data(), world::kRegionVolume);
+    std::memcpy(materials, h->materials.data(), sizeof(uint32_t) * h->materials.size());
+    std::memcpy(minefield, h->minefield.data(), h->minefield.size());
 }
 
 // ---- camera / uniforms ------------------------------------------------------------------------------
@@ -193,6 +198,7 @@ int rth_game_set_world(void* g, const uint32_t* materials, const uint8_t* minefi
     return static_cast<game::Game*>(g)->set_world(materials, minefield);
 }
 int rth_game_generate_world(void* g, uint64_t seed) { return static_cast<game::Game*>(g)->generate_world(seed); }
+int rth_game_generate_world_r(void* g, uint64_t seed, int region) { return static_cast<game::Game*>(g)->generate_world(seed, region); }
 
 void* rth_create_instance(const RtConfig* cfg, const uint8_t* blue_noise_rgba8, void* g, char* err, size_t err_len) {
     std::string msg;

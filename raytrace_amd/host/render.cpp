@@ -32,7 +32,7 @@ Pipeline* create_instance(const RtConfig& cfg, const uint8_t* blue_noise_rgba8, 
         return nullptr;
     };
     if (!blue_noise_rgba8) { if (error) *error = "blue noise table is required"; return nullptr; }
-    if (!game.has_world()) game.generate_world(0x5EED);
+    if (!game.has_world() || game.world_region() != cfg.region) game.generate_world(0x5EED, cfg.region);
     RtContext* ctx = nullptr;
     if (rt_create(&cfg, &ctx) != RT_OK) return fail("rt_create", nullptr);
     if (rt_upload_world(ctx, game.world_materials(), game.world_minefield()) != RT_OK) return fail("rt_upload_world", ctx);
@@ -40,6 +40,7 @@ Pipeline* create_instance(const RtConfig& cfg, const uint8_t* blue_noise_rgba8, 
     Pipeline* p = new Pipeline();
     p->ctx_ = ctx;
     p->spp_ = cfg.spp > 0 ? cfg.spp : 1;
+    p->region_ = cfg.region;
     std::memset(&p->uniforms_, 0, sizeof(p->uniforms_));
     p->uniforms_.lr[0] = -64; p->uniforms_.lr[1] = -64;    // create_raytrace_uniform_data, render_data.rs:146-147;
     p->uniforms_.lso[0] = -64; p->uniforms_.lso[1] = -64;  // overwritten on the first draw_frame (pipeline.rs:203-207)
@@ -50,7 +51,7 @@ Pipeline::~Pipeline() { rt_destroy(ctx_); }
 
 void Pipeline::enable_terrain_streaming(uint64_t seed, const std::string& storage_dir) {
     chunks_.reset(new world::ChunkStorage(storage_dir, seed));
-    tum_.reset(new TerrainUploadManager());
+    tum_.reset(new TerrainUploadManager(region_));
 }
 
 const char* Pipeline::last_error() const { return rt_last_error(ctx_); }
@@ -130,10 +131,13 @@ Game::Game(int argc, const char* const* argv) {
     }
 }
 
-int Game::generate_world(uint64_t seed) {
-    materials_.assign(world::kRegionVolume, 0);
-    minefield_.assign(world::kRegionVolume, 0);
-    world::assemble_region_procedural(seed, materials_.data(), minefield_.data());
+int Game::generate_world(uint64_t seed, int region) {
+    if (region != 256 && region != 512 && region != 1024) return RT_ERR_INVALID_ARG;
+    const size_t n = (size_t)region * region * region;
+    materials_.assign(n, 0);
+    minefield_.assign(n, 0);
+    world::assemble_region_procedural(seed, materials_.data(), minefield_.data(), region);
+    region_ = region;
     return RT_OK;
 }
 
@@ -141,6 +145,7 @@ int Game::set_world(const uint32_t* materials, const uint8_t* minefield) {
     if (!materials || !minefield) return RT_ERR_INVALID_ARG;
     materials_.assign(materials, materials + world::kRegionVolume);
     minefield_.assign(minefield, minefield + world::kRegionVolume);
+    region_ = world::kRegion;
     return RT_OK;
 }
 

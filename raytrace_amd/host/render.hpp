@@ -37,7 +37,8 @@ class Game {
     Game(int argc, const char* const* argv);
     const render::Camera& borrow_camera() const { return camera; }   // mod.rs:111-113
     float get_sun_angle() const { return sun_angle; }                // mod.rs:123-125
-    int generate_world(uint64_t seed);
+    int generate_world(uint64_t seed, int region = RT_ROOT_BLOCK_SIZE);   // region: 256 = the reference; 512 / 1024 = extension
+    int world_region() const { return region_; }
     int set_world(const uint32_t* materials, const uint8_t* minefield);
     bool has_world() const { return !materials_.empty(); }
     const uint32_t* world_materials() const { return materials_.data(); }
@@ -49,6 +50,7 @@ class Game {
  private:
     std::vector<uint32_t> materials_;
     std::vector<uint8_t> minefield_;
+    int region_ = RT_ROOT_BLOCK_SIZE;
 };
 
 }  // namespace rt::game
@@ -78,6 +80,7 @@ class Pipeline {
     RtContext* ctx_ = nullptr;
     RtUniforms uniforms_{};            // RenderData::raytrace_uniform_data, render_data.rs:134-162
     int spp_ = 1;
+    int region_ = RT_ROOT_BLOCK_SIZE;
     int render_offset_[3] = {0, 0, 0}; // TerrainUploadManager::get_render_offset (terrain_upload.rs:30-47)
     std::unique_ptr<TerrainUploadManager> tum_;
     std::unique_ptr<world::ChunkStorage> chunks_;

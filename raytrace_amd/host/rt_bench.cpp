@@ -1,16 +1,23 @@
 // rt_bench — headless counterpart of the reference's interactive binary (src/bin/main.rs:8-57): builds the Game
 // (six optional positional floats `x y z heading pitch sun_angle`, src/game/mod.rs:45-52), creates the renderer, then
 // loops draw_frame and prints the rolling average / maximum frame time of the last 120 frames
-// (RingBufferAverage, src/util.rs:175-221; printout main.rs:42-47).
+// (RingBufferAverage, src/util.rs:175-221; printout main.rs:42-47) — followed by ONE JSON line with the metrics SURVEY.md 5
+// asks of the bench binary (config, rays, ms, Mrays/s).
 //
 //   rt_bench [x y z heading pitch sun] [--width W] [--height H] [--spp N] [--depth D] [--frames F]
-//            [--noise tests/golden/blue_noise_512.rgba] [--device I]
+//            [--noise tests/golden/blue_noise_512.rgba] [--device I] [--gpus N] [--gather] [--overlap]
+//
+// --gpus N (one host thread per device, ncclCommInitAll through rt_comm_init_all): device i renders the tiles t % N == i and
+// every frame ends with rt_gather_gbuffer to device 0, which assembles the full frame in the library's own planes.
+// --gather runs that frame-end step with N = 1 too (a one-rank communicator).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "render.hpp"
@@ -42,11 +49,21 @@ class RingBufferAverage {
     size_t filled_, next_;
 };
 
+RtConfig make_config(int width, int height, int spp, int depth, int device, int rank, int world, uint32_t flags) {
+    RtConfig cfg{};
+    cfg.struct_size = sizeof(cfg);
+    cfg.width = width; cfg.height = height; cfg.region = RT_ROOT_BLOCK_SIZE; cfg.spp = spp; cfg.depth = depth;
+    cfg.device = device; cfg.tile_rank = rank; cfg.tile_world = world; cfg.kernel = RT_KERNEL_DEFAULT;
+    cfg.flags = flags;
+    return cfg;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     int width = 1024, height = 1024;   // WINDOW_WIDTH / WINDOW_HEIGHT, src/render/constants.rs:9-10
-    int spp = 1, depth = 2, frames = 240, device = 0;
+    int spp = 1, depth = 2, frames = 240, device = 0, gpus = 1;
+    bool gather = false, overlap = false;
     std::string noise_path = "tests/golden/blue_noise_512.rgba";
     std::vector<const char*> positional = {argv[0]};
     for (int i = 1; i < argc; i++) {
@@ -57,9 +74,14 @@ int main(int argc, char** argv) {
         else if (want("--depth")) depth = std::atoi(argv[++i]);
         else if (want("--frames")) frames = std::atoi(argv[++i]);
         else if (want("--device")) device = std::atoi(argv[++i]);
+        else if (want("--gpus")) gpus = std::atoi(argv[++i]);
         else if (want("--noise")) noise_path = argv[++i];
+        else if (std::strcmp(argv[i], "--gather") == 0) gather = true;
+        else if (std::strcmp(argv[i], "--overlap") == 0) overlap = true;
         else positional.push_back(argv[i]);
     }
+    if (gpus < 1 || frames < 1) { std::fprintf(stderr, "--gpus and --frames must be >= 1\n"); return 2; }
+    if (gpus > 1) gather = true;
     rt::game::Game game((int)positional.size(), positional.data());
 
     std::vector<uint8_t> noise(RT_NOISE_BYTES);
@@ -73,35 +95,95 @@ int main(int argc, char** argv) {
     std::printf("Creating renderer (and world.)\n");                 // main.rs:10
     auto t0 = std::chrono::steady_clock::now();
     game.generate_world(0x5EED);
-    RtConfig cfg{};
-    cfg.struct_size = sizeof(cfg);
-    cfg.width = width; cfg.height = height; cfg.region = RT_ROOT_BLOCK_SIZE; cfg.spp = spp; cfg.depth = depth;
-    cfg.device = device; cfg.tile_rank = 0; cfg.tile_world = 1; cfg.kernel = RT_KERNEL_DEFAULT;
-    cfg.flags = RT_FLAG_CACHE_PRIMARY;
     std::string err;
-    rt::render::Pipeline* pipeline = rt::render::create_instance(cfg, noise.data(), game, &err);
-    if (!pipeline) {
-        std::fprintf(stderr, "create_instance failed: %s\n", err.c_str());
-        return 1;
+
+    // exact ray count of one frame (a counting context, outside the timed loop): the JSON line's Mrays/s is rays actually traced
+    unsigned long long rays_per_frame = 0;
+    {
+        RtConfig ccfg = make_config(width, height, spp, depth, device, 0, 1, RT_FLAG_CACHE_PRIMARY | RT_FLAG_COUNTERS);
+        rt::render::Pipeline* cp = rt::render::create_instance(ccfg, noise.data(), game, &err);
+        if (!cp) { std::fprintf(stderr, "create_instance failed: %s\n", err.c_str()); return 1; }
+        RtCounters cn{};
+        if (cp->draw_frame(game) != RT_OK || cp->wait() != RT_OK || rt_get_counters(cp->context(), &cn) != RT_OK) {
+            std::fprintf(stderr, "counting frame failed: %s\n", cp->last_error());
+            delete cp;
+            return 1;
+        }
+        rays_per_frame = cn.rays;
+        delete cp;
+    }
+
+    std::vector<rt::render::Pipeline*> pipes((size_t)gpus, nullptr);
+    std::vector<void*> comms((size_t)gpus, nullptr);
+    std::vector<int> devices((size_t)gpus);
+    for (int g = 0; g < gpus; g++) devices[(size_t)g] = device + g;
+    for (int g = 0; g < gpus; g++) {
+        RtConfig cfg = make_config(width, height, spp, depth, devices[(size_t)g], g, gpus, RT_FLAG_CACHE_PRIMARY);
+        pipes[(size_t)g] = rt::render::create_instance(cfg, noise.data(), game, &err);
+        if (!pipes[(size_t)g]) {
+            std::fprintf(stderr, "create_instance failed on device %d: %s\n", devices[(size_t)g], err.c_str());
+            return 1;
+        }
+    }
+    if (gather) {
+        int rc = rt_comm_init_all(gpus, devices.data(), comms.data());
+        if (rc != RT_OK) { std::fprintf(stderr, "rt_comm_init_all failed (%d): %s\n", rc, rt_last_error(nullptr)); return 1; }
     }
     std::printf("Created in %fs.\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());   // main.rs:13
 
     RingBufferAverage perf(120);                                      // main.rs:16
-    auto frame_timer = std::chrono::steady_clock::now();
-    for (int f = 0; f < frames; f++) {
-        auto now = std::chrono::steady_clock::now();
-        double millis = std::chrono::duration<double, std::milli>(now - frame_timer).count();
-        frame_timer = now;
-        if (f > 0) perf.push_sample(millis);
-        int rc = pipeline->draw_frame(game);                          // main.rs:52
-        if (rc != RT_OK) {
-            std::fprintf(stderr, "draw_frame failed (%d): %s\n", rc, pipeline->last_error());
-            delete pipeline;
-            return 1;
+    std::atomic<int> failed{0};
+    double total_ms = 0.0;
+    // one host thread per device; thread 0 keeps the reference's frame-time statistics (main.rs:42-47)
+    auto worker = [&](int g) {
+        rt::render::Pipeline* p = pipes[(size_t)g];
+        auto frame_timer = std::chrono::steady_clock::now();
+        const auto loop_start = frame_timer;
+        for (int f = 0; f < frames && !failed.load(); f++) {
+            if (g == 0) {
+                auto now = std::chrono::steady_clock::now();
+                double millis = std::chrono::duration<double, std::milli>(now - frame_timer).count();
+                frame_timer = now;
+                if (f > 0) perf.push_sample(millis);
+            }
+            int rc = p->draw_frame(game);                             // main.rs:52
+            if (rc == RT_OK && gather) rc = rt_gather_gbuffer(p->context(), comms[(size_t)g], 0, nullptr, overlap ? 1 : 0);
+            if (rc != RT_OK) {
+                std::fprintf(stderr, "frame %d failed on device %d (%d): %s\n", f, devices[(size_t)g], rc, p->last_error());
+                failed.store(1);
+            }
         }
+        if (rt_sync(p->context()) != RT_OK) failed.store(1);
+        if (g == 0) total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - loop_start).count();
+    };
+    std::vector<std::thread> threads;
+    for (int g = 1; g < gpus; g++) threads.emplace_back(worker, g);
+    worker(0);
+    for (auto& t : threads) t.join();
+
+    int exit_code = failed.load() ? 1 : 0;
+    if (!exit_code) {
+        std::printf("%.3fms / %.3fms\n", perf.average(), perf.max());    // main.rs:45-46: average / max
+        // a checksum of the assembled frame's depth plane shows that the gather delivered pixels (0 without --gather)
+        unsigned long long checksum = 0;
+        if (gather) {
+            std::vector<uint16_t> depth_plane((size_t)width * height);
+            if (rt_frame_readback(pipes[0]->context(), RT_BUF_DEPTH_R16UI, depth_plane.data(), depth_plane.size() * 2) == RT_OK)
+                for (uint16_t v : depth_plane) checksum += v;
+            else { std::fprintf(stderr, "rt_frame_readback failed: %s\n", pipes[0]->last_error()); exit_code = 1; }
+        }
+        const double ms = total_ms / frames;
+        std::printf("{\"binary\": \"rt_bench\", \"config\": {\"width\": %d, \"height\": %d, \"spp\": %d, \"depth\": %d, \"gpus\": %d, "
+                    "\"gather\": \"%s\", \"pose\": [%g, %g, %g, %g, %g], \"sun_angle\": %g}, \"frames\": %d, \"rays_per_frame\": %llu, "
+                    "\"ms_per_frame\": %.4f, \"avg_ms_last_120\": %.4f, \"max_ms_last_120\": %.4f, \"mrays_per_s\": %.2f, "
+                    "\"depth_plane_checksum\": %llu}\n",
+                    width, height, spp, depth, gpus, gather ? (overlap ? "rccl-overlapped" : "rccl-serial") : "none",
+                    game.camera.origin[0], game.camera.origin[1], game.camera.origin[2], game.camera.heading, game.camera.pitch,
+                    game.sun_angle, frames, rays_per_frame, ms, perf.average(), perf.max(), (double)rays_per_frame / (ms * 1e3), checksum);
     }
-    pipeline->wait();
-    std::printf("%.3fms / %.3fms\n", perf.average(), perf.max());    // main.rs:45-46: average / max
-    delete pipeline;
-    return 0;
+    for (int g = 0; g < gpus; g++) {
+        if (comms[(size_t)g]) rt_comm_destroy(comms[(size_t)g]);
+        delete pipes[(size_t)g];
+    }
+    return exit_code;
 }

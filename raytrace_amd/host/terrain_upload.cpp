@@ -6,30 +6,33 @@ namespace rt::render {
 namespace {
 constexpr int kSlice = RT_SLICE_SIZE;                          // 16
 constexpr int kChunk = RT_CHUNK_SIZE;                          // 64
-constexpr int kRegion = RT_ROOT_BLOCK_SIZE;                    // 256
-constexpr int kSlicesPerRegion = kRegion / kSlice;             // 16
-constexpr int kRegionChunks = RT_ROOT_CHUNK_SIZE;              // 4
 inline long floor_div(long a, long b) { long q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 }  // namespace
 
 void Position::render_offset(long out[3]) const {
-    for (int a = 0; a < 3; a++) out[a] = (origin[a] + kRegionChunks / 2) * kChunk + (long)num_loaded_slices[a] * kSlice;
+    for (int a = 0; a < 3; a++) out[a] = (origin[a] + region_chunks / 2) * kChunk + (long)num_loaded_slices[a] * kSlice;
 }
 
-TerrainUploadManager::TerrainUploadManager()
-    : material_upload_buffer_((size_t)kSlice * kRegion * kRegion), minefield_upload_buffer_((size_t)kSlice * kRegion * kRegion) {}
+TerrainUploadManager::TerrainUploadManager(int region)
+    : region_(region), slices_per_region_(region / kSlice), region_chunks_(region / kChunk),
+      material_upload_buffer_((size_t)kSlice * region * region), minefield_upload_buffer_((size_t)kSlice * region * region) {
+    for (Position* p : {&cpu_position_, &gpu_position_}) {
+        p->region_chunks = region_chunks_;
+        for (int a = 0; a < 3; a++) p->origin[a] = -region_chunks_ / 2;     // Position::default, :39-47
+    }
+}
 
 void TerrainUploadManager::request_increase(Axis axis) {
     // the slab at index num_loaded_slices is replaced by the same slab of the NEXT region (origin + 4 chunks), then the count grows
     const int m = (int)axis;
     Request r{};
     for (int a = 0; a < 3; a++) { r.origin[a] = cpu_position_.origin[a]; r.num_slices[a] = cpu_position_.num_loaded_slices[a]; }
-    r.origin[m] += kRegionChunks;
+    r.origin[m] += region_chunks_;
     r.axis = axis;
     cpu_position_.num_loaded_slices[m] += 1;
-    if (cpu_position_.num_loaded_slices[m] == kSlicesPerRegion) {
+    if (cpu_position_.num_loaded_slices[m] == slices_per_region_) {
         cpu_position_.num_loaded_slices[m] = 0;
-        cpu_position_.origin[m] += kRegion / kChunk;
+        cpu_position_.origin[m] += region_chunks_;
     }
     r.new_position = cpu_position_;
     queue_.push_back(r);
@@ -39,8 +42,8 @@ void TerrainUploadManager::request_decrease(Axis axis) {
     // step the count back first, then reload that slab from the CURRENT region
     const int m = (int)axis;
     if (cpu_position_.num_loaded_slices[m] == 0) {
-        cpu_position_.num_loaded_slices[m] = kSlicesPerRegion;
-        cpu_position_.origin[m] -= kRegion / kChunk;
+        cpu_position_.num_loaded_slices[m] = slices_per_region_;
+        cpu_position_.origin[m] -= region_chunks_;
     }
     cpu_position_.num_loaded_slices[m] -= 1;
     Request r{};
@@ -68,11 +71,12 @@ int TerrainUploadManager::setup_next_request(world::ChunkStorage& chunks, const 
 }
 
 // The slab holds, on the main axis m, the 16 world voxels starting at request.origin[m]*64 + num_slices[m]*16, and on
-// each other axis a the 256-voxel window starting at request.origin[a]*64 + num_slices[a]*16, every voxel stored at texel
-// (voxel - origin*64) mod 256 — the texture's toroidal addressing.  Chunk pieces never straddle the wrap because 256 is a
+// each other axis a the R-voxel window starting at request.origin[a]*64 + num_slices[a]*16, every voxel stored at texel
+// (voxel - origin*64) mod R — the texture's toroidal addressing.  Chunk pieces never straddle the wrap because R is a
 // multiple of the chunk size.
 int TerrainUploadManager::upload_slice(world::ChunkStorage& chunks, const SliceSink& sink, const Request& rq) {
     const int m = (int)rq.axis;
+    const int kRegion = region_;
     world::Dims3 shape{kRegion, kRegion, kRegion};
     (m == 0 ? shape.x : (m == 1 ? shape.y : shape.z)) = kSlice;
     const world::Dims3 cdims{kChunk, kChunk, kChunk};

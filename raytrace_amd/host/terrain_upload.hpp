@@ -17,6 +17,7 @@ enum class Axis { X = 0, Y = 1, Z = 2 };
 struct Position {
     long origin[3] = {-RT_ROOT_CHUNK_SIZE / 2, -RT_ROOT_CHUNK_SIZE / 2, -RT_ROOT_CHUNK_SIZE / 2};
     int num_loaded_slices[3] = {0, 0, 0};
+    int region_chunks = RT_ROOT_CHUNK_SIZE;    // chunks per region edge: 4 in the reference (ROOT_CHUNK_SIZE); R / 64 for the larger regions
     void render_offset(long out[3]) const;     // :29-36
 };
 
@@ -26,7 +27,9 @@ using SliceSink = std::function<int(int, int, const uint32_t*, const uint8_t*)>;
 
 class TerrainUploadManager {
  public:
-    TerrainUploadManager();
+    // region: edge of the toroidal region texture, 256 in the reference (ROOT_BLOCK_SIZE); 512 and 1024 are the build's extension
+    explicit TerrainUploadManager(int region = RT_ROOT_BLOCK_SIZE);
+    int region() const { return region_; }
     void request_increase(Axis axis);                          // :289-318
     void request_decrease(Axis axis);                          // :320-345
     void request_move_towards(const long desired_center[3]);   // :347-367
@@ -40,9 +43,10 @@ class TerrainUploadManager {
  private:
     struct Request { long origin[3]; int num_slices[3]; Axis axis; Position new_position; };   // :11-19
     int upload_slice(world::ChunkStorage& chunks, const SliceSink& sink, const Request& request);   // :84-275
+    int region_, slices_per_region_, region_chunks_;
     std::deque<Request> queue_;
     Position cpu_position_, gpu_position_;
-    std::vector<uint32_t> material_upload_buffer_;   // one slab: 16 x 256 x 256 (:65-82)
+    std::vector<uint32_t> material_upload_buffer_;   // one slab: 16 x R x R (:65-82)
     std::vector<uint8_t> minefield_upload_buffer_;
 };
 

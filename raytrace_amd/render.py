@@ -161,6 +161,31 @@ class Context:
         arr = (C.c_void_p * 6)(*[C.c_void_p(p) if p else None for p in frame_dev_ptrs])
         self._check(self._lib.rt_untile_gbuffer(self._h, C.c_void_p(gathered_dev_ptr), int(world), arr))
 
+    # -- multi-GPU frame assembly (rt_gather_gbuffer) ------------------------------------------------------
+    def comm_init_rank(self, unique_id):
+        """ncclCommInitRank(tile_world, unique_id, tile_rank) on this context's device; returns the communicator handle."""
+        comm = C.c_void_p()
+        buf = (C.c_char * len(unique_id)).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.rt_comm_init_rank(self._h, buf, len(unique_id), C.byref(comm)))
+        return comm.value
+
+    def gather_gbuffer(self, comm, root, frame_dev_ptrs=None, overlapped=False):
+        """Every rank's six reference-format planes -> `root` over RCCL on the context's stream, un-tiled there into the six
+        row-major device planes frame_dev_ptrs (root only)."""
+        arr = (C.c_void_p * 6)(*[C.c_void_p(p) if p else None for p in frame_dev_ptrs]) if frame_dev_ptrs else None
+        self._check(self._lib.rt_gather_gbuffer(self._h, C.c_void_p(comm) if comm else None, int(root), arr, 1 if overlapped else 0))
+
+    def frame_ptr(self, buffer_id):
+        return self._lib.rt_frame_ptr(self._h, int(buffer_id))
+
+    def frame_readback(self, buffer_id):
+        """Plane `buffer_id` of the frame rt_gather_gbuffer assembled in the library's own planes (frames_dev = NULL)."""
+        dt, ch = BUFFER_FORMATS[buffer_id]
+        W, H = self.cfg.width, self.cfg.height
+        out = np.empty((H, W, ch) if ch > 1 else (H, W), dtype=dt)
+        self._check(self._lib.rt_frame_readback(self._h, int(buffer_id), _p(out), out.nbytes))
+        return out
+
     # -- post passes (pipeline.rs:98-123) ----------------------------------------------------------------
     def denoise(self, faithful=True):
         self._check(self._lib.rt_denoise(self._h, 1 if faithful else 0))
@@ -272,8 +297,10 @@ class Game:
         if rc != 0:
             raise RtError(rc, "set_world")
 
-    def generate_world(self, seed=0x5EED):
-        _lib.host().rth_game_generate_world(self._h, C.c_uint64(int(seed)))
+    def generate_world(self, seed=0x5EED, region=256):
+        rc = _lib.host().rth_game_generate_world_r(self._h, C.c_uint64(int(seed)), int(region))
+        if rc != 0:
+            raise RtError(rc, "generate_world: region must be 256, 512 or 1024")
 
     def close(self):
         if self._h:
@@ -361,3 +388,17 @@ def camera_uniforms(origin, heading, pitch, sun_angle=0.0, seed=1, lr=(0, 0, 0))
 
 
 DEFAULT_POSE = dict(origin=(-30.0, -128.0, 100.0), heading=math.pi / 2, pitch=0.0, sun_angle=0.0)  # game/mod.rs:53-55
+
+
+def comm_unique_id():
+    """ncclGetUniqueId: 128 opaque bytes one rank creates and the host hands to every rank (rt_comm_unique_id)."""
+    buf = (C.c_char * 128)()
+    rc = _lib.amd().rt_comm_unique_id(buf, 128)
+    if rc != 0:
+        raise RtError(rc, _lib.amd().rt_last_error(None).decode())
+    return bytes(buf)
+
+
+def comm_destroy(comm):
+    if comm:
+        _lib.amd().rt_comm_destroy(C.c_void_p(comm))

@@ -181,8 +181,11 @@ class HostTerrainUploadManager:
     """TerrainUploadManager (terrain_upload.rs:49-368) driving a HOST copy of the toroidal region — what the pipeline
     does on the device through rt_upload_slice, for CPU tests."""
 
-    def __init__(self, seed=DEFAULT_SEED):
-        self._h = C.c_void_p(_lib.host().rth_tum_new(C.c_uint64(seed)))
+    def __init__(self, seed=DEFAULT_SEED, region=256):
+        self.region_size = int(region)
+        self._h = C.c_void_p(_lib.host().rth_tum_new_r(C.c_uint64(seed), self.region_size))
+        if not self._h:
+            raise ValueError("region must be 256, 512 or 1024")
 
     def request_increase(self, axis):
         _lib.host().rth_tum_request(self._h, int(axis), 1)
@@ -206,10 +209,11 @@ class HostTerrainUploadManager:
         return tuple(o[:])
 
     def region(self):
-        mats = np.zeros(REGION_VOLUME, dtype=np.uint32)
-        mine = np.zeros(REGION_VOLUME, dtype=np.uint8)
+        R = self.region_size
+        mats = np.zeros(R ** 3, dtype=np.uint32)
+        mine = np.zeros(R ** 3, dtype=np.uint8)
         _lib.host().rth_tum_region(self._h, _p(mats), _p(mine))
-        return mats.reshape(256, 256, 256), mine.reshape(256, 256, 256)
+        return mats.reshape(R, R, R), mine.reshape(R, R, R)
 
     def close(self):
         if self._h:
@@ -223,24 +227,25 @@ class HostTerrainUploadManager:
             pass
 
 
-def toroidal_region(render_offset, seed=DEFAULT_SEED):
+def toroidal_region(render_offset, seed=DEFAULT_SEED, region=256):
     """Expected texture content for a render offset (multiples of 16): texel t on each axis holds the world voxel v with
-    (v + 128) mod 256 == t inside the window [offset-128, offset+128).  Built from whole chunks, independently of the
-    TerrainUploadManager."""
+    (v + R/2) mod R == t inside the window [offset-R/2, offset+R/2) (R = 256 in the reference).  Built from whole chunks,
+    independently of the TerrainUploadManager."""
+    R, half = int(region), int(region) // 2
     cs = ChunkStorage("", seed)
-    mats = np.zeros((256, 256, 256), dtype=np.uint32)
-    mine = np.zeros((256, 256, 256), dtype=np.uint8)
-    lo = [int(o) - 128 for o in render_offset]
-    cr = [range(l // 64, (l + 255) // 64 + 1) for l in lo]
+    mats = np.zeros((R, R, R), dtype=np.uint32)
+    mine = np.zeros((R, R, R), dtype=np.uint8)
+    lo = [int(o) - half for o in render_offset]
+    cr = [range(l // 64, (l + R - 1) // 64 + 1) for l in lo]
     for cz in cr[2]:
         for cy in cr[1]:
             for cx in cr[0]:
                 m, f = cs.borrow_packed_chunk_data(cx, cy, cz)
                 c0 = (cx * 64, cy * 64, cz * 64)
-                s = [slice(max(c0[a], lo[a]) - c0[a], min(c0[a] + 64, lo[a] + 256) - c0[a]) for a in range(3)]
+                s = [slice(max(c0[a], lo[a]) - c0[a], min(c0[a] + 64, lo[a] + R) - c0[a]) for a in range(3)]
                 if any(x.stop <= x.start for x in s):
                     continue
-                t = [(c0[a] + s[a].start + 128) % 256 for a in range(3)]
+                t = [(c0[a] + s[a].start + half) % R for a in range(3)]
                 d = [slice(t[a], t[a] + (s[a].stop - s[a].start)) for a in range(3)]
                 mats[d[2], d[1], d[0]] = m[s[2], s[1], s[0]]
                 mine[d[2], d[1], d[0]] = f[s[2], s[1], s[0]]

@@ -251,20 +251,28 @@ def test_pipeline_mirror_draw_frame(blue_noise):
     g.close()
 
 
-def test_upload_slice_matches_full_upload(procedural_region, blue_noise):
-    """rt_upload_slice (terrain_upload.rs:84-275): patching 16-thick slabs on each axis equals uploading the edited region."""
-    mats, mine = procedural_region
-    rng = np.random.default_rng(3)
+@pytest.mark.parametrize("region,flags", [(256, 0), (256, abi.RT_FLAG_TRUSTED_WORLD), (512, 0)])
+def test_upload_slice_matches_full_upload(procedural_region, blue_noise, region, flags):
+    """rt_upload_slice (terrain_upload.rs:84-275): patching 16-thick slabs on each axis — terrain of another seed, so mixed
+    bricks, materials and every minefield value move — equals uploading the edited region; the slab path re-tiles only the
+    slab (any region size).  A slab with a minefield value above 30 is rejected and leaves no drawable world."""
+    if region == 256:
+        mats, mine = procedural_region
+        origin = (-20.0, -120.0, 60.0)
+    else:
+        mats, mine = world.generate_region(world.DEFAULT_SEED, region=region)
+        origin = (-40.0, -240.0, 120.0)
+    other_m, other_f = world.generate_region(world.DEFAULT_SEED + 1, region=region)
     mats2, mine2 = mats.copy(), mine.copy()
-    # carve an empty slab along each axis (minefield 6 / material 0 is a valid "all empty" patch)
-    edits = [(0, 96), (1, 32), (2, 160)]
+    R = region
+    edits = [(0, 96), (1, 32), (2, R // 2 + 16), (0, R - 16), (2, 0), (1, R // 2)]
     for axis, off in edits:
         sl = [slice(None)] * 3
         sl[2 - axis] = slice(off, off + 16)     # arrays are [z, y, x]
-        mats2[tuple(sl)] = 0
-        mine2[tuple(sl)] = 6
-    u = _uniforms(origin=(-20.0, -120.0, 60.0), pitch=-0.3, seed=4)
-    cfg = render.make_config(64, 64, spp=1, depth=2)
+        mats2[tuple(sl)] = other_m[tuple(sl)]
+        mine2[tuple(sl)] = other_f[tuple(sl)]
+    u = _uniforms(origin=origin, pitch=-0.3, seed=4)
+    cfg = render.make_config(64, 64, spp=1, depth=2, region=region, flags=flags | abi.RT_FLAG_CACHE_PRIMARY)
     with render.Context(cfg) as ctx:
         ctx.upload_world(mats, mine)
         ctx.upload_noise(blue_noise)
@@ -276,10 +284,23 @@ def test_upload_slice_matches_full_upload(procedural_region, blue_noise):
         ctx.sync()
         a = ctx.readback_all()
         with pytest.raises(render.RtError):
-            ctx.upload_slice(3, 0, np.zeros(16 * 65536, np.uint32), np.zeros(16 * 65536, np.uint8))
+            ctx.upload_slice(3, 0, np.zeros(16 * R * R, np.uint32), np.zeros(16 * R * R, np.uint8))
         with pytest.raises(render.RtError):
-            ctx.upload_slice(0, 8, np.zeros(16 * 65536, np.uint32), np.zeros(16 * 65536, np.uint8))
-    cpu, _ = po.render(mats2, mine2, blue_noise, u, 64, 64, 1, 2)
+            ctx.upload_slice(0, 8, np.zeros(16 * R * R, np.uint32), np.zeros(16 * R * R, np.uint8))
+        if not flags & abi.RT_FLAG_TRUSTED_WORLD:
+            bad = np.full(16 * R * R, 6, np.uint8)
+            bad[12345] = 31
+            with pytest.raises(render.RtError):
+                ctx.upload_slice(1, 64, np.zeros(16 * R * R, np.uint32), bad)
+            with pytest.raises(render.RtError):
+                ctx.draw_frame(u)            # the region holds a rejected slab: nothing to draw until it is replaced
+            ctx.upload_slice(1, 64, np.ascontiguousarray(mats2[:, 64:80, :]), np.ascontiguousarray(mine2[:, 64:80, :]))
+            ctx.draw_frame(u)
+            ctx.sync()
+            b = ctx.readback_all()
+            for name in a:
+                assert np.array_equal(a[name], b[name], equal_nan=True), name
+    cpu, _ = po.render(mats2, mine2, blue_noise, u, 64, 64, 1, 2, region=region)
     for name in cpu:
         assert np.array_equal(a[name], cpu[name], equal_nan=True), name
 
@@ -385,7 +406,7 @@ def test_bench_rccl_path_single_rank():
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    for overlap, port in (("1", "29537"), ("0", "29538")):   # pipelined gather (default) and the serial one
+    for overlap, port in (("1", "29537"), ("0", "29538")):   # pipelined gather and the serial one (default)
         env = dict(os.environ, RT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                    RT_BENCH_OVERLAP=overlap)
         env.pop("RT_BENCH_BACKEND", None)
@@ -394,7 +415,7 @@ def test_bench_rccl_path_single_rank():
         j2 = json.loads([l for l in forced.stdout.splitlines() if l.startswith("{")][-1])
         assert j1["config"]["frame_sha256_16"] == j2["config"]["frame_sha256_16"]
         assert j1["config"]["rays_per_frame"] == j2["config"]["rays_per_frame"]
-        assert j2["config"]["gather"] == ("overlapped with the next frame" if overlap == "1" else "serial")
+        assert ("overlapped" in j2["config"]["gather"]) == (overlap == "1") and "rt_gather_gbuffer" in j2["config"]["gather"]
 
 
 @pytest.fixture(scope="module")
@@ -439,7 +460,6 @@ def test_region_size_validation(native_built):
         render.Context(render.make_config(64, 64, region=512, kernel=abi.RT_KERNEL_WAVEFRONT))
 
 
-@pytest.mark.skipif(not os.environ.get("RT_TEST_REGION_1024"), reason="5 GiB scene; set RT_TEST_REGION_1024=1 to run")
 def test_region_1024_matches_oracle(blue_noise, native_built):
     """Config C5's scene size: 1024^3 (1 GiB minefield + 4 GiB materials — larger than the 256 MiB Infinity Cache)."""
     mats, mine = world.generate_region(world.DEFAULT_SEED, region=1024)
@@ -545,3 +565,198 @@ def test_headline_frame_equals_the_oracle(procedural_region, blue_noise):
                            flags=abi.RT_FLAG_COUNTERS | abi.RT_FLAG_CACHE_PRIMARY)
     _compare(gpu, cpu)
     assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
+
+
+# ---- BASELINE.json config C4: 3840x2160, spp 256, depth 8 (sixteen k_persist-sized batches on the old kernel, one launch on
+# ---- k_paths), as one context and as the eight-way tile split the 8-GPU run uses -------------------------------------------
+C4 = (3840, 2160, 256, 8)
+
+
+def _frame_hash(planes):
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(planes):
+        h.update(np.ascontiguousarray(planes[name]).tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module")
+def c4_frame(procedural_region, blue_noise):
+    """The C4 frame from one whole-frame context on the default kernel (cached primaries), drawn twice."""
+    mats, mine = procedural_region
+    W, H, spp, depth = C4
+    u = _uniforms(seed=1)
+    cfg = render.make_config(W, H, spp=spp, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(u)
+        ctx.sync()
+        first = ctx.readback_all()
+        ctx.draw_frame(u)
+        ctx.sync()
+        second = ctx.readback_all()
+    return u, first, second
+
+
+def test_c4_frame_properties_and_oracle_bands(procedural_region, blue_noise, c4_frame):
+    """3840x2160 spp 256 depth 8 through RT_KERNEL_DEFAULT: determinism, primary-plane identity with an spp-1 depth-0 frame,
+    counter identities of the counting build (also un-cached: same pixels), and two 8-row bands against the oracle."""
+    mats, mine = procedural_region
+    W, H, spp, depth = C4
+    u, a1, a2 = c4_frame
+    for name in a1:
+        assert np.array_equal(a1[name], a2[name], equal_nan=True), name
+    p1, _ = _render_gpu(mats, mine, blue_noise, u, W, H, 1, 0, abi.RT_KERNEL_DEFAULT, flags=0)
+    for name in ("depth_r16", "normal_r8", "albedo_rgba8", "emission_rgba8", "fog_rgba8", "depth_f32", "fog_f32"):
+        assert np.array_equal(a1[name], p1[name], equal_nan=True), name
+    b1, cn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, abi.RT_KERNEL_DEFAULT,
+                         flags=abi.RT_FLAG_COUNTERS | abi.RT_FLAG_CACHE_PRIMARY)
+    for name in a1:
+        assert np.array_equal(a1[name], b1[name], equal_nan=True), name
+    assert cn.frames == 1 and cn.pixels == W * H and cn.rays_primary == W * H
+    assert cn.minefield_fetches == cn.rays + cn.iterations
+    assert cn.rays_shadow == cn.rays_diffuse and cn.noise_fetches == cn.rays_shadow + spp
+    assert cn.hits + cn.sky_exits + cn.limit_exits == cn.rays and cn.material_fetches == cn.hits
+    for rows in ((536, 544), (1336, 1344)):     # terrain near the horizon, and sky + distant terrain
+        cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth, rows=rows)
+        for name in cpu:
+            assert np.array_equal(a1[name][rows[0]:rows[1]], cpu[name][rows[0]:rows[1]], equal_nan=True), (name, rows)
+
+
+def test_c4_eight_way_tile_split_reassembles(procedural_region, blue_noise, c4_frame):
+    """The layout of the 8-GPU run on one GPU: eight contexts render tiles t % 8 == rank of the C4 frame, their G-buffer blocks
+    are laid out rank-major (what the gather produces) and rt_untile_gbuffer scatters them: same frame, bit for bit."""
+    import torch
+    mats, mine = procedural_region
+    W, H, spp, depth = C4
+    u, whole, _ = c4_frame
+    world_n = 8
+    dev = torch.device("cuda", 0)
+    gathered = None
+    keep = None
+    for r in range(world_n):
+        cfg = render.make_config(W, H, spp=spp, depth=depth, tile_rank=r, tile_world=world_n, flags=abi.RT_FLAG_CACHE_PRIMARY)
+        c = render.Context(cfg)
+        c.upload_world(mats, mine)
+        c.upload_noise(blue_noise)
+        c.draw_frame(u)
+        c.sync()
+        gbytes = c.gbuffer_bytes()
+        if gathered is None:
+            gathered = torch.zeros(world_n * gbytes, dtype=torch.uint8, device=dev)
+        view = torch.as_tensor(_DevBytes(c.gbuffer_ptr(), gbytes), device=dev)
+        gathered[r * gbytes:(r + 1) * gbytes].copy_(view)
+        torch.cuda.synchronize()
+        if r == 0:
+            keep = c
+        else:
+            c.destroy()
+    ids = list(range(abi.RT_BUF_FOG_RGBA8 + 1))
+    frames = []
+    for b in ids:
+        dt, ch = abi.BUFFER_FORMATS[b]
+        frames.append(torch.zeros(W * H * np.dtype(dt).itemsize * ch, dtype=torch.uint8, device=dev))
+    torch.cuda.synchronize()
+    keep.untile_gbuffer(gathered.data_ptr(), world_n, [fr.data_ptr() for fr in frames])
+    keep.sync()
+    torch.cuda.synchronize()
+    for b, fr in zip(ids, frames):
+        dt, ch = abi.BUFFER_FORMATS[b]
+        got = fr.cpu().numpy().view(dt).reshape((H, W, ch) if ch > 1 else (H, W))
+        assert np.array_equal(got, whole[abi.BUFFER_NAMES[b]]), abi.BUFFER_NAMES[b]
+    keep.destroy()
+
+
+class _DevBytes:
+    """Zero-copy view of device memory for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def test_bench_gather_delivers_the_frame_of_its_own_step():
+    """Every step renders a different frame (--vary-seed, no warm-up): the frame rank 0 assembled after the last step must be
+    the frame of THAT step's seed — a gather that ran ahead of its frame's kernels (or an un-tile ahead of its gather) would
+    deliver an older one.  RCCL path with one rank (serial and overlapped), and the two-rank gloo rehearsal."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    size = ["--width", "200", "--height", "120", "--spp", "4", "--depth", "3", "--no-cpu-baseline"]
+
+    def line(cmd, env=None):
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    want = line([sys.executable, "bench.py", "--gpus", "1", "--seed", "7", "--steps", "1", "--warmup", "0"] + size)
+    prev = line([sys.executable, "bench.py", "--gpus", "1", "--seed", "6", "--steps", "1", "--warmup", "0"] + size)
+    assert want["config"]["frame_sha256_16"] != prev["config"]["frame_sha256_16"]
+    vary = ["--seed", "4", "--vary-seed", "--steps", "4", "--warmup", "0"]      # frames of seeds 4, 5, 6, 7
+    for overlap, port in (("0", "29541"), ("1", "29542")):
+        env = dict(os.environ, RT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                   RT_BENCH_OVERLAP=overlap)
+        env.pop("RT_BENCH_BACKEND", None)
+        got = line([sys.executable, "bench.py", "--gpus", "1"] + vary + size, env)
+        assert got["config"]["seed"] == 7 and got["config"]["frame_sha256_16"] == want["config"]["frame_sha256_16"], overlap
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_SINGLE_DEVICE="1")
+    got = line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29543", "bench.py", "--gpus", "2", "--no-c4"] + vary + size, env)
+    assert got["n_gpus"] == 2 and got["config"]["frame_sha256_16"] == want["config"]["frame_sha256_16"]
+
+
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_gather_gbuffer_through_the_c_abi(procedural_region, blue_noise, overlapped):
+    """rt_comm_unique_id / rt_comm_init_rank / rt_gather_gbuffer / rt_comm_destroy with the one-rank communicator a one-GPU
+    box allows: the block travels through RCCL (send to and receive from itself on the context's stream) into the staging
+    area and from there into six caller-owned planes; three frames in a row, each checked against the context's own planes."""
+    import torch
+    mats, mine = procedural_region
+    W, H, spp, depth = 136, 72, 2, 3
+    dev = torch.device("cuda", 0)
+    cfg = render.make_config(W, H, spp=spp, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        comm = ctx.comm_init_rank(render.comm_unique_id())
+        ids = list(range(abi.RT_BUF_FOG_RGBA8 + 1))
+        frames = []
+        for b in ids:
+            dt, ch = abi.BUFFER_FORMATS[b]
+            frames.append(torch.zeros(W * H * np.dtype(dt).itemsize * ch, dtype=torch.uint8, device=dev))
+        torch.cuda.synchronize()
+        for seed in (3, 4, 5):
+            ctx.draw_frame(_uniforms(seed=seed))
+            ctx.gather_gbuffer(comm, 0, [fr.data_ptr() for fr in frames], overlapped=overlapped)
+            ctx.sync()                 # both streams
+            for b, fr in zip(ids, frames):
+                assert np.array_equal(fr.cpu().numpy(), ctx.readback(b).reshape(-1).view(np.uint8)), (seed, abi.BUFFER_NAMES[b])
+        with pytest.raises(render.RtError):
+            ctx.gather_gbuffer(comm, 1, [fr.data_ptr() for fr in frames])      # root outside the communicator
+        render.comm_destroy(comm)
+
+
+def test_rt_bench_binary_runs_and_reports_metrics(native_built):
+    """The headless counterpart of src/bin/main.rs: six positional floats (x y z heading pitch sun_angle, game/mod.rs:45-52),
+    a short run, the reference-style `avg / max` line (main.rs:45-46) and one JSON line with config, rays, ms and Mrays/s —
+    plain, and with the frame-end gather on a one-rank communicator (what --gpus N does per device), serial and overlapped."""
+    import json
+    import subprocess
+    from tests.conftest import ROOT
+    exe = os.path.join(ROOT, "raytrace_amd", "rt_bench")
+    base = [exe, "-30", "-128", "100", "1.5707964", "-0.2", "0.3", "--width", "256", "--height", "128", "--spp", "2", "--depth", "3", "--frames", "8"]
+    lines = {}
+    for tag, extra in (("plain", []), ("gather", ["--gather"]), ("overlap", ["--gather", "--overlap"])):
+        r = subprocess.run(base + extra, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = r.stdout.splitlines()
+        assert any(l.endswith("ms") and " / " in l for l in out), out
+        j = json.loads([l for l in out if l.startswith("{")][-1])
+        assert j["binary"] == "rt_bench" and j["frames"] == 8 and j["config"]["gpus"] == 1
+        assert j["config"]["pose"][:3] == [-30, -128, 100] and abs(j["config"]["sun_angle"] - 0.3) < 1e-6
+        assert j["rays_per_frame"] > 256 * 128 and j["ms_per_frame"] > 0 and j["mrays_per_s"] > 0
+        lines[tag] = j
+    assert lines["plain"]["depth_plane_checksum"] == 0
+    assert lines["gather"]["depth_plane_checksum"] == lines["overlap"]["depth_plane_checksum"] > 0
+    assert lines["gather"]["rays_per_frame"] == lines["plain"]["rays_per_frame"]

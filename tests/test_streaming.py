@@ -99,6 +99,49 @@ def test_terrain_upload_manager_region_content(moves):
     t.close()
 
 
+def test_terrain_upload_manager_region_512():
+    """The same manager on the 512^3 extension (8 chunks, 32 slabs per region edge): slab requests across the +x wrap and on
+    -z, content against the independently assembled toroidal window."""
+    t = world.HostTerrainUploadManager(region=512)
+    assert t.get_render_offset() == (0, 0, 0)
+    moves = [(0, 1)] * 2 + [(2, 0)]
+    for axis, inc in moves:
+        (t.request_increase if inc else t.request_decrease)(axis)
+    while t.pending():
+        t.setup_next_request()
+    off = t.get_render_offset()
+    assert off == (32, 0, -16)
+    mats, mine = t.region()
+    emats, emine = world.toroidal_region(off, region=512)
+    assert np.array_equal(mats, emats) and np.array_equal(mine, emine)
+    t.close()
+
+
+@pytest.mark.gpu
+def test_streaming_pipeline_region_512(blue_noise):
+    """Pipeline::draw_frame with terrain streaming on a 512^3 region: three frames, one slab each through the incremental
+    rt_upload_slice, every frame against the oracle fed the expected toroidal window."""
+    g = render.Game(args=(120, -200, 140, 1.6, -0.2, 0.3))
+    g.generate_world(world.DEFAULT_SEED, region=512)
+    cfg = render.make_config(64, 48, spp=1, depth=2, region=512)
+    p = render.create_instance(cfg, g, blue_noise)
+    p.enable_terrain_streaming(world.DEFAULT_SEED)
+    seen = []
+    for frame in range(3):
+        p.draw_frame(g)
+        p.wait()
+        u = p.uniforms()
+        seen.append(tuple(u.lr))
+        mats, mine = world.toroidal_region(tuple(u.lr), region=512)
+        cpu, _ = po.render(mats, mine, blue_noise, u, 64, 48, 1, 2, region=512)
+        gpu = p.context.readback_all()
+        for name in cpu:
+            assert np.array_equal(gpu[name], cpu[name], equal_nan=True), (frame, name)
+    assert seen == [(16, 0, 0), (32, 0, 0), (48, 0, 0)]
+    p.close()
+    g.close()
+
+
 @pytest.mark.gpu
 def test_streaming_pipeline_follows_the_camera(blue_noise):
     """Pipeline::draw_frame with the TerrainUploadManager (pipeline.rs:174-207): the camera starts 60 voxels from the

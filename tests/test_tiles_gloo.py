@@ -57,18 +57,33 @@ def _worker(rank, world, port, width, height, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("width,height", [(64, 48), (100, 60)])
-def test_two_rank_gather_and_untile(width, height):
+@pytest.mark.parametrize("width,height,world", [(64, 48, 2), (100, 60, 2), (200, 120, 8)])
+def test_two_rank_gather_and_untile(width, height, world):
+    """world = 8 is the driver's scaling run: with tiles_x % 8 == 0 (1920 -> 240, 3840 -> 480; here 200 -> 25 is not) the
+    round-robin deal degenerates to fixed 8-pixel columns per rank — still balanced, still a partition."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, width, height, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, width, height, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_eight_way_deal_of_the_benchmark_frames_is_columns():
+    """1920x1080 and 3840x2160 have tiles_x divisible by 8, so rank r of 8 owns tile columns r, r+8, ...: every rank gets the
+    same number of tiles from every tile row (sky and terrain alike) — the balance the interleave is there for."""
+    for (w, h) in ((1920, 1080), (3840, 2160)):
+        tx, ty = tiles.tile_grid(w, h)
+        assert tx % 8 == 0
+        for r in range(8):
+            t = tiles.tiles_of_rank(w, h, r, 8)
+            assert np.all(t % tx % 8 == r)
+            rows = np.bincount(t // tx, minlength=ty)
+            assert rows.min() == rows.max() == tx // 8
 
 
 def test_tile_partition_properties():
