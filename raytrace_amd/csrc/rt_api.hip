@@ -89,6 +89,7 @@ struct RtContext {
     uint32_t persist_chunk = 0;   // RT_PERSIST_CHUNK: paths per cursor atomic (multiple of 64); 0 = automatic
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
     int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2), 3 = k_paths (RT_KERNEL_PATHS)
+    bool paths_by_size = false;   // RT_KERNEL_DEFAULT: k_paths for launches with enough work, k_persist for small ones
     float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
     bool lut_valid = false;
     int primary_version = 2;      // 1 = k_primary (thread per pixel), 2 = k_primary2 (nibble map in LDS); RT_PRIMARY_V
@@ -319,6 +320,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     {
         // RT_KERNEL_DEFAULT = k_paths (two paths, four ray slots per lane, branch-free step loop); the frames it does not
         // cover run on k_persist (rt_draw_frame decides per frame: lr is a per-frame uniform)
+        c->paths_by_size = cfg->kernel == RT_KERNEL_DEFAULT;
         c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PATHS : cfg->kernel;
         if (c->kernel == RT_KERNEL_PERSISTENT2) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 2; }   // same pipeline, other path kernel
         if (c->kernel == RT_KERNEL_PATHS) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 3; }
@@ -572,7 +574,13 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 pa.pl = ctx->ppl; pa.counters = ctx->d_counters;
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 0);
-                    if (ctx->persist_version == 3 && cache && f.lr_zero != 0 && f.logr == 8)
+                    // k_paths pays for its two contexts per lane once there is enough work to keep them filled: measured
+                    // crossover against k_persist at ~8 M paths per launch (1080p: spp 4 loses 10 %, spp 16 wins 9 %; the
+                    // reference's own 1024^2 1-spp frame: 0.31 vs 0.23 ms).  The worklist length lives on the device; the
+                    // pixel count bounds it.
+                    // (RT_KERNEL_PATHS asks for k_paths whatever the size.)
+                    const bool big = !ctx->paths_by_size || (uint64_t)ctx->npix_pad * ns >= (12ull << 20);
+                    if (ctx->persist_version == 3 && cache && f.lr_zero != 0 && f.logr == 8 && big)
                         e = rtd::launch_paths(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->num_cus, ctx->stream);
                     else
                         e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->persist_version == 2 ? 2 : 1, ctx->num_cus, ctx->stream);

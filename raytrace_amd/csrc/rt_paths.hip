@@ -116,7 +116,9 @@ __device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, ui
 
 }  // namespace
 
-// STK: where the albedo stack of the two paths lives — 0 = LDS (depth <= 4: three levels per path), 1 = global memory.
+// STK: where the albedo stack of the two paths lives — 0 = LDS (depth <= 4: three levels per path: the 24 KiB the nibble map
+// and the tables leave hold exactly 2 x 3 rows), 1 = global memory.  (Deeper frames with the first three levels in LDS and the
+// rest in global memory were measured on the 4K spp-256 depth-8 frame: 8.63 instead of 8.51 ms per launch.)
 template <bool COUNT, int STK>
 __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, PersistArgs a) {
     __shared__ uint32_t s_coarse[kCoarseWords];
