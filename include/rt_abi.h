@@ -299,6 +299,12 @@ int rt_finalize_planes(RtContext* ctx, const void* albedo_rgba8, const void* emi
 /* The traversal implementation the context runs (what RT_KERNEL_DEFAULT resolved to); negative RtStatus on a null context. */
 int rt_kernel_in_use(RtContext* ctx);
 
+/* Device self-tests.  RT_SELFTEST_DENOISE_DIVISION: the denoise passes compute weight / (distance + normal + 1)
+ * (bilateral_denoise.comp:31) with a reciprocal and one residual correction; *result = number of quotients, over the complete
+ * domain of that expression (37 weights x 131072 denominators), that differ from IEEE division on this device (expected 0). */
+#define RT_SELFTEST_DENOISE_DIVISION 1
+int rt_selftest(RtContext* ctx, int which, uint64_t* result);
+
 int rt_get_counters(RtContext* ctx, RtCounters* out);
 int rt_reset_counters(RtContext* ctx);
 int rt_get_timing(RtContext* ctx, RtTiming* out);

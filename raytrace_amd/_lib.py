@@ -17,7 +17,7 @@ ABI_SYMBOLS = (
     "rt_untile_gbuffer", "rt_denoise", "rt_finalize", "rt_denoise_planes", "rt_finalize_planes", "rt_kernel_in_use", "rt_get_counters", "rt_reset_counters", "rt_get_timing",
     "rt_abi_version",
     "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_gather_gbuffer", "rt_frame_ptr",
-    "rt_frame_readback",
+    "rt_frame_readback", "rt_selftest",
 )
 
 _amd = None
@@ -85,6 +85,8 @@ def amd():
         lib.rt_frame_ptr.restype = P
         lib.rt_frame_readback.argtypes = [P, C.c_int, P, C.c_size_t]
         lib.rt_frame_readback.restype = C.c_int
+        lib.rt_selftest.argtypes = [P, C.c_int, C.POINTER(C.c_uint64)]
+        lib.rt_selftest.restype = C.c_int
         for name in ("rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_gather_gbuffer"):
             getattr(lib, name).restype = C.c_int
         for name in ("rt_upload_world", "rt_upload_slice", "rt_upload_noise", "rt_draw_frame", "rt_sync", "rt_readback",

@@ -867,6 +867,21 @@ int rt_gather_gbuffer(RtContext* ctx, void* comm_, int root, void* const* frames
     return RT_OK;
 }
 
+int rt_selftest(RtContext* ctx, int which, uint64_t* result) {
+    if (!ctx || !result) return RT_ERR_INVALID_ARG;
+    if (which != RT_SELFTEST_DENOISE_DIVISION) return fail(ctx, RT_ERR_INVALID_ARG, "rt_selftest: unknown test");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long* d = nullptr;
+    RT_HIP(ctx, dev_alloc(ctx, &d, 1));
+    RT_HIP(ctx, hipMemsetAsync(d, 0, sizeof(*d), ctx->stream));
+    RT_HIP(ctx, rtd::launch_selftest_dn_div(d, ctx->stream));
+    unsigned long long h = 0;
+    RT_HIP(ctx, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *result = h;
+    return RT_OK;
+}
+
 void* rt_frame_ptr(RtContext* ctx, int id) {
     if (!ctx || id < 0 || id > RT_BUF_FOG_RGBA8) return nullptr;
     return ctx->frame_planes[id];

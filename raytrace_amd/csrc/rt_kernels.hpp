@@ -111,6 +111,7 @@ hipError_t launch_denoise_prepare(const void* lighting, const void* depth, const
                                   hipStream_t st);
 hipError_t launch_denoise(const void* work_in, int W, int H, int size, bool swapped, bool last, void* work_out, void* lighting,
                           hipStream_t st);
+hipError_t launch_selftest_dn_div(unsigned long long* mismatches_dev, hipStream_t st);
 hipError_t launch_finalize(const void* albedo, const void* emission, const void* fog, const void* lighting, const void* depth,
                            const uint32_t* noise, int W, int H, void* out_bgra8, hipStream_t st);
 

@@ -175,6 +175,12 @@ class Context:
         arr = (C.c_void_p * 6)(*[C.c_void_p(p) if p else None for p in frame_dev_ptrs]) if frame_dev_ptrs else None
         self._check(self._lib.rt_gather_gbuffer(self._h, C.c_void_p(comm) if comm else None, int(root), arr, 1 if overlapped else 0))
 
+    def selftest(self, which=1):
+        """rt_selftest: RT_SELFTEST_DENOISE_DIVISION (1) -> number of inexact quotients over the denoise division's domain."""
+        out = C.c_uint64(0)
+        self._check(self._lib.rt_selftest(self._h, int(which), C.byref(out)))
+        return int(out.value)
+
     def frame_ptr(self, buffer_id):
         return self._lib.rt_frame_ptr(self._h, int(buffer_id))
 

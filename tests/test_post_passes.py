@@ -118,3 +118,40 @@ def test_gpu_post_passes_match_oracle(procedural_region, blue_noise, W, H, spp, 
     assert np.array_equal(fin, exp_fin), "finalize differs at %d bytes" % int(np.count_nonzero(fin != exp_fin))
     # near pixels exist in this pose only if the camera hugs terrain; make sure the quirk path ran at least as a copy
     assert (den[..., 3][g["normal_r8"] == 16] == 4096).all()
+
+
+@pytest.mark.gpu
+def test_denoise_division_is_exact_on_its_whole_domain(native_built):
+    """The denoise passes replace the IEEE division of bilateral_denoise.comp:31 by a reciprocal and one residual correction;
+    rt_selftest compares the two over EVERY value the expression can take (37 weights x {k/64 + 1, k/64 + 11 : k < 65536}) on
+    the device the suite runs on: not one quotient may differ."""
+    with render.Context(render.make_config(64, 64)) as ctx:
+        assert ctx.selftest(1) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(333, 77), (40, 30)])
+def test_gpu_denoise_tiled_and_direct_dispatches_agree_with_the_oracle(procedural_region, blue_noise, W, H, monkeypatch):
+    """Frame sizes that are not multiples of the 32x8 tile, smaller than the size-8 halo on one axis, both descriptor-set
+    modes: the LDS-tiled dispatches (sizes 1, 2, 4, 8), the direct one (RT_DENOISE_UNTILED) and the oracle give the same bits."""
+    mats, mine = procedural_region
+    u = po.camera_uniforms((-30.0, -128.0, 100.0), np.pi / 2, -0.25, 0.3, 9)
+    cfg = render.make_config(W, H, spp=1, depth=2, flags=abi.RT_FLAG_CACHE_PRIMARY)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        for faithful in (True, False):
+            outs = []
+            for untiled in (False, True):
+                if untiled:
+                    monkeypatch.setenv("RT_DENOISE_UNTILED", "1")
+                else:
+                    monkeypatch.delenv("RT_DENOISE_UNTILED", raising=False)
+                ctx.draw_frame(u)
+                ctx.sync()
+                g = ctx.readback_all()
+                ctx.denoise(faithful=faithful)
+                ctx.sync()
+                outs.append(ctx.readback(abi.RT_BUF_LIGHTING_RGBA16))
+            exp = po.denoise(g["lighting_rgba16"], g["depth_r16"], g["normal_r8"], faithful=faithful)
+            assert np.array_equal(outs[0], exp) and np.array_equal(outs[1], exp), faithful
