@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-KERNEL_NAMES = {"paths": "k_paths", "persistent": "k_persist", "persistent2": "k_persist2", "wavefront": "k_trace", "mega": "k_mega"}
+KERNEL_NAMES = {"seq": "k_seq", "paths": "k_paths", "persistent": "k_persist", "persistent2": "k_persist2", "wavefront": "k_trace", "mega": "k_mega"}
 
 
 def parse_args():
@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1, help="seed of the frame's first sample (pipeline.rs:201 starts at 1)")
     ap.add_argument("--vary-seed", action="store_true",
                     help="frame i is drawn with seed + i (every step renders a different frame; the hash is the last one's)")
-    ap.add_argument("--kernel", choices=["default", "paths", "persistent", "persistent2", "wavefront", "mega"], default="default")
+    ap.add_argument("--kernel", choices=["default", "seq", "paths", "persistent", "persistent2", "wavefront", "mega"], default="default")
     ap.add_argument("--no-cache-primary", dest="cache_primary", action="store_false",
                     help="re-trace the (seed-independent) primary ray for every sample, like spp reference frames would")
     ap.set_defaults(cache_primary=True)
@@ -155,7 +155,7 @@ def main():
         os.environ.setdefault("RT_RESERVE_CUS", "8")
     reserve_cus = int(os.environ.get("RT_RESERVE_CUS", "0") or 0)
 
-    kernel = {"default": abi.RT_KERNEL_DEFAULT, "paths": abi.RT_KERNEL_PATHS, "persistent": abi.RT_KERNEL_PERSISTENT,
+    kernel = {"default": abi.RT_KERNEL_DEFAULT, "seq": abi.RT_KERNEL_SEQ, "paths": abi.RT_KERNEL_PATHS, "persistent": abi.RT_KERNEL_PERSISTENT,
               "persistent2": abi.RT_KERNEL_PERSISTENT2, "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
     noise = np.fromfile(os.path.join(ROOT, "tests", "golden", "blue_noise_512.rgba"), dtype=np.uint8)
@@ -200,9 +200,9 @@ def main():
         # ---- exact ray / byte counts of one frame (deterministic; outside the timed region) --------------------
         cctx = make_ctx(abi.RT_FLAG_COUNTERS)
         # the report names the kernel the library actually runs (RT_KERNEL_DEFAULT resolves in rt_create)
-        rec["kernel"] = {abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent", abi.RT_KERNEL_PERSISTENT2: "persistent2",
+        rec["kernel"] = {abi.RT_KERNEL_SEQ: "seq", abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent", abi.RT_KERNEL_PERSISTENT2: "persistent2",
                          abi.RT_KERNEL_WAVEFRONT: "wavefront", abi.RT_KERNEL_MEGA: "mega"}[cctx.kernel_in_use()]
-        if rec["kernel"] == "paths" and not (args.cache_primary and REGION == 256):
+        if rec["kernel"] in ("paths", "seq") and not (args.cache_primary and REGION == 256):
             rec["kernel"] = "persistent"      # k_paths covers cached-primary frames of the 256^3 region; the rest runs on k_persist
         cctx.draw_frame(u0)
         cctx.sync()
@@ -213,7 +213,7 @@ def main():
         rec["trace_bytes"] = cn.minefield_fetches + 4 * cn.material_fetches
         rec["balg"] = cn.algorithmic_bytes()
         rec["ref_rays"] = cn.rays + (SPP - 1) * cn.pixels if args.cache_primary else cn.rays
-        if rec["kernel"] in ("paths", "persistent", "persistent2") and args.cache_primary and D >= 1:
+        if rec["kernel"] in ("seq", "paths", "persistent", "persistent2") and args.cache_primary and D >= 1:
             # the dominant kernel walks only shadow/diffuse rays; the primary prepass (k_primary2) is a separate launch,
             # untimed for the roofline: subtract its share, measured with a depth-0 counting frame
             c0 = make_ctx(abi.RT_FLAG_COUNTERS, depth=0)

@@ -89,6 +89,7 @@ struct RtContext {
     uint32_t persist_chunk = 0;   // RT_PERSIST_CHUNK: paths per cursor atomic (multiple of 64); 0 = automatic
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
     int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2), 3 = k_paths (RT_KERNEL_PATHS)
+    int seq_nc = 3;               // k_seq: paths per lane (RT_SEQ_NC)
     bool paths_by_size = false;   // RT_KERNEL_DEFAULT: k_paths for launches with enough work, k_persist for small ones
     float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
     bool lut_valid = false;
@@ -296,7 +297,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (cfg->depth < 0 || cfg->depth > RT_MAX_DEPTH) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: depth out of range");
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: bad tile_rank/tile_world");
-    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_PATHS)
+    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_SEQ)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown kernel");
 
     int ndev = 0;
@@ -324,6 +325,8 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PATHS : cfg->kernel;
         if (c->kernel == RT_KERNEL_PERSISTENT2) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 2; }   // same pipeline, other path kernel
         if (c->kernel == RT_KERNEL_PATHS) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 3; }
+        if (c->kernel == RT_KERNEL_SEQ) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 4; }
+        if (const char* s = getenv("RT_SEQ_NC")) { int v = atoi(s); if (v == 2 || v == 3) c->seq_nc = v; }
     }
     RT_HIP_CREATE(hipSetDevice(c->device));
     hipDeviceProp_t prop;
@@ -381,10 +384,11 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= 4096) c->persist_chunk = (uint32_t)v & ~63u; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
-    if (c->persist_threshold == 0) c->persist_threshold = c->persist_version == 2 ? 40u : 32u;   // measured optima
+    if (c->persist_threshold == 0) c->persist_threshold = c->persist_version == 2 ? 40u : (c->persist_version == 4 ? 36u : 32u);   // measured optima
+    if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 24u;   // k_seq: waiting contexts that trigger the re-arm block
     if (c->kernel == RT_KERNEL_PERSISTENT) {
         RT_HIP_CREATE(dev_alloc(c, &c->pcursor, kCursorWords + 1));   // 8 cursor lines + the worklist count
-        RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)2 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));
+        RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)4 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));   // up to 3 paths per lane
         RT_HIP_CREATE(dev_alloc(c, &c->worklist, (size_t)c->npix_pad));
         RT_HIP_CREATE(dev_alloc(c, &c->phx, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->phy, (size_t)c->npix_pad));
         RT_HIP_CREATE(dev_alloc(c, &c->phz, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->pinfo, (size_t)c->npix_pad));
@@ -580,7 +584,9 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                     // pixel count bounds it.
                     // (RT_KERNEL_PATHS asks for k_paths whatever the size.)
                     const bool big = !ctx->paths_by_size || (uint64_t)ctx->npix_pad * ns >= (12ull << 20);
-                    if (ctx->persist_version == 3 && cache && f.lr_zero != 0 && f.logr == 8 && big)
+                    if (ctx->persist_version == 4 && cache && f.lr_zero != 0 && f.logr == 8)
+                        e = rtd::launch_seq(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->seq_nc, ctx->num_cus, ctx->stream);
+                    else if (ctx->persist_version == 3 && cache && f.lr_zero != 0 && f.logr == 8 && big)
                         e = rtd::launch_paths(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->num_cus, ctx->stream);
                     else
                         e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->persist_version == 2 ? 2 : 1, ctx->num_cus, ctx->stream);
@@ -902,6 +908,7 @@ int rt_kernel_in_use(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 2) return RT_KERNEL_PERSISTENT2;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 3) return RT_KERNEL_PATHS;
+    if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 4) return RT_KERNEL_SEQ;
     return ctx->kernel;
 }
 
@@ -921,8 +928,9 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
                         "(avg lanes %.1f, sky lanes %.1f)\n", d.dbg_loop_iters, d.dbg_s_execs, d.dbg_s_execs ? (double)d.dbg_s_lanes / d.dbg_s_execs : 0.0,
                 d.dbg_f_execs, d.dbg_f_execs ? (double)d.dbg_f_lanes / d.dbg_f_execs : 0.0, d.dbg_passes,
                 d.dbg_passes ? (double)d.dbg_pass_lanes / d.dbg_passes : 0.0, d.dbg_passes ? (double)d.dbg_sky_lanes / d.dbg_passes : 0.0),
-        fprintf(stderr, "[rt] raw: loop_iters %llu s_lanes %llu f_lanes %llu passes %llu pass_lanes %llu\n", d.dbg_loop_iters, d.dbg_s_lanes,
-                d.dbg_f_lanes, d.dbg_passes, d.dbg_pass_lanes);
+        fprintf(stderr, "[rt] raw: loop_iters %llu s_lanes %llu f_lanes %llu passes %llu pass_lanes %llu s_execs %llu f_execs %llu\n", d.dbg_loop_iters, d.dbg_s_lanes,
+                d.dbg_f_lanes, d.dbg_passes, d.dbg_pass_lanes, d.dbg_s_execs, d.dbg_f_execs),
+        fprintf(stderr, "[rt] raw2: sky_lanes %llu\n", d.dbg_sky_lanes);
     return RT_OK;
 }
 

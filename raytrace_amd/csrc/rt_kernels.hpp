@@ -90,6 +90,10 @@ hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, con
 hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nworkgroups,
                         hipStream_t st);
 
+// k_seq (rt_seq.hip): nc = paths per lane (2 or 3); same coverage as k_paths
+hipError_t launch_seq(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nc, int nworkgroups,
+                      hipStream_t st);
+
 hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
                           uint32_t* coarse, uint32_t* bad_flag, int logr, hipStream_t st);
 hipError_t launch_flatten_slab(const uint8_t* mine_slab, const uint32_t* mat_slab, uint8_t* mine_sw, uint32_t* mat_sw, uint32_t* coarse,

@@ -59,14 +59,15 @@ def test_gpu_reproduces_golden(case, kernel, scenes_cache, blue_noise):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PATHS, abi.RT_KERNEL_SEQ])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_gpu_paths_kernel_reproduces_golden(case, scenes_cache, blue_noise):
+def test_gpu_paths_kernel_reproduces_golden(case, kernel, scenes_cache, blue_noise):
     """RT_KERNEL_PATHS (cached primaries: the configuration RT_KERNEL_DEFAULT runs) on the golden frames; frames with lr != 0
     take its k_persist fallback."""
     scene, W, H, spp, depth, origin, heading, pitch, sun, seed, lr = CASES[case]
     mats, mine = scenes_cache(scene)
     u = render.camera_uniforms(origin, heading, pitch, sun, seed, lr)
-    cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=abi.RT_KERNEL_PATHS, flags=abi.RT_FLAG_CACHE_PRIMARY)
+    cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=kernel, flags=abi.RT_FLAG_CACHE_PRIMARY)
     with render.Context(cfg) as ctx:
         ctx.upload_world(mats, mine)
         ctx.upload_noise(blue_noise)

@@ -63,7 +63,7 @@ def _cached_counters(mats, mine, noise, u, W, H, spp, depth, ccn, **kw):
     return d
 
 
-PATH_KERNELS = [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2, abi.RT_KERNEL_PATHS]
+PATH_KERNELS = [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2, abi.RT_KERNEL_PATHS, abi.RT_KERNEL_SEQ]
 
 CASES = [
     # W, H, spp, depth
