@@ -199,13 +199,11 @@ def main():
         rec = {}
         # ---- exact ray / byte counts of one frame (deterministic; outside the timed region) --------------------
         cctx = make_ctx(abi.RT_FLAG_COUNTERS)
-        # the report names the kernel the library actually runs (RT_KERNEL_DEFAULT resolves in rt_create)
-        rec["kernel"] = {abi.RT_KERNEL_SEQ: "seq", abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent", abi.RT_KERNEL_PERSISTENT2: "persistent2",
-                         abi.RT_KERNEL_WAVEFRONT: "wavefront", abi.RT_KERNEL_MEGA: "mega"}[cctx.kernel_in_use()]
-        if rec["kernel"] in ("paths", "seq") and not (args.cache_primary and REGION == 256):
-            rec["kernel"] = "persistent"      # k_paths covers cached-primary frames of the 256^3 region; the rest runs on k_persist
         cctx.draw_frame(u0)
         cctx.sync()
+        # the report names the kernel the frame actually ran on (RT_KERNEL_DEFAULT picks k_paths / k_persist per frame)
+        rec["kernel"] = {abi.RT_KERNEL_SEQ: "seq", abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent", abi.RT_KERNEL_PERSISTENT2: "persistent2",
+                         abi.RT_KERNEL_WAVEFRONT: "wavefront", abi.RT_KERNEL_MEGA: "mega"}[cctx.kernel_in_use()]
         cn = cctx.counters()
         cctx.destroy()
         rec["rays"] = cn.rays

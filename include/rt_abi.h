@@ -298,7 +298,9 @@ int rt_denoise_planes(RtContext* ctx, void* lighting_rgba16, const void* depth_r
 int rt_finalize_planes(RtContext* ctx, const void* albedo_rgba8, const void* emission_rgba8, const void* fog_rgba8,
                        const void* lighting_rgba16, const void* depth_r16, void* out_bgra8);
 
-/* The traversal implementation the context runs (what RT_KERNEL_DEFAULT resolved to); negative RtStatus on a null context. */
+/* The traversal implementation the context runs: after a frame, the kernel its path launches actually ran on (RT_KERNEL_DEFAULT
+ * and RT_KERNEL_PATHS/SEQ choose per frame: launch size, lr, primary cache, region); before the first frame, what the
+ * configuration resolved to.  Negative RtStatus on a null context. */
 int rt_kernel_in_use(RtContext* ctx);
 
 /* Device self-tests.  RT_SELFTEST_DENOISE_DIVISION: the denoise passes compute weight / (distance + normal + 1)

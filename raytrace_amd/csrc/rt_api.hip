@@ -91,6 +91,7 @@ struct RtContext {
     int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2), 3 = k_paths (RT_KERNEL_PATHS)
     int seq_nc = 3;               // k_seq: paths per lane (RT_SEQ_NC)
     bool paths_by_size = false;   // RT_KERNEL_DEFAULT: k_paths for launches with enough work, k_persist for small ones
+    int last_path_kernel = 0;     // RtKernel the most recent frame's path launches ran on (0 = no frame yet)
     float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
     bool lut_valid = false;
     int primary_version = 2;      // 1 = k_primary (thread per pixel), 2 = k_primary2 (nibble map in LDS); RT_PRIMARY_V
@@ -584,11 +585,16 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                     // pixel count bounds it.
                     // (RT_KERNEL_PATHS asks for k_paths whatever the size.)
                     const bool big = !ctx->paths_by_size || (uint64_t)ctx->npix_pad * ns >= (12ull << 20);
-                    if (ctx->persist_version == 4 && cache && f.lr_zero != 0 && f.logr == 8)
+                    if (ctx->persist_version == 4 && cache && f.lr_zero != 0 && f.logr == 8) {
+                        ctx->last_path_kernel = RT_KERNEL_SEQ;
                         e = rtd::launch_seq(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->seq_nc, ctx->num_cus, ctx->stream);
-                    else if (ctx->persist_version == 3 && cache && f.lr_zero != 0 && f.logr == 8 && big)
+                    } else if (ctx->persist_version == 3 && cache && f.lr_zero != 0 && f.logr == 8 && big) {
+                        ctx->last_path_kernel = RT_KERNEL_PATHS;
                         e = rtd::launch_paths(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->num_cus, ctx->stream);
-                    else
+                    } else {
+                        ctx->last_path_kernel = ctx->persist_version == 2 ? RT_KERNEL_PERSISTENT2 : RT_KERNEL_PERSISTENT;
+                    }
+                    if (ctx->last_path_kernel == RT_KERNEL_PERSISTENT || ctx->last_path_kernel == RT_KERNEL_PERSISTENT2)
                         e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->persist_version == 2 ? 2 : 1, ctx->num_cus, ctx->stream);
                 }
                 if (e == hipSuccess) {
@@ -906,6 +912,7 @@ int rt_frame_readback(RtContext* ctx, int id, void* dst, size_t bytes) {
 
 int rt_kernel_in_use(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
+    if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->last_path_kernel != 0) return ctx->last_path_kernel;   // what the last frame ran
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 2) return RT_KERNEL_PERSISTENT2;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 3) return RT_KERNEL_PATHS;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 4) return RT_KERNEL_SEQ;
