@@ -13,7 +13,7 @@ def source_sha16():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "raytrace_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
+        if name.endswith((".hip", ".hpp")) and name != "rt_api.hip":      # device code only: rt_api.hip is host-side
             h.update(open(os.path.join(d, name), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "rt_math.h"), "rb").read())
     return h.hexdigest()[:16]
