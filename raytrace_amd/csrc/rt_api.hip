@@ -89,7 +89,7 @@ struct RtContext {
     uint32_t persist_chunk = 0;   // RT_PERSIST_CHUNK: paths per cursor atomic (multiple of 64); 0 = automatic
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
     int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2), 3 = k_paths (RT_KERNEL_PATHS)
-    int seq_nc = 3;               // k_seq: paths per lane (RT_SEQ_NC)
+    int seq_nc = 2;               // k_seq: paths per lane (RT_SEQ_NC; 2 measured faster than 3)
     bool paths_by_size = false;   // RT_KERNEL_DEFAULT: k_paths for launches with enough work, k_persist for small ones
     int last_path_kernel = 0;     // RtKernel the most recent frame's path launches ran on (0 = no frame yet)
     float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
@@ -387,7 +387,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
     if (c->persist_threshold == 0)   // measured optima (k_paths: 28 with four steps between looks at the parked lanes; its k_persist fallback shares it)
         c->persist_threshold = c->persist_version == 2 ? 40u : (c->persist_version == 4 ? 36u : (c->persist_version == 3 ? 28u : 32u));
-    if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 24u;   // k_seq: waiting contexts that trigger the re-arm block
+    if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 16u;   // k_seq: waiting contexts that trigger the re-arm block
     if (c->kernel == RT_KERNEL_PERSISTENT) {
         RT_HIP_CREATE(dev_alloc(c, &c->pcursor, kCursorWords + 1));   // 8 cursor lines + the worklist count
         RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)4 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));   // up to 3 paths per lane

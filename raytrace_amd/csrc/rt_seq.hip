@@ -10,11 +10,13 @@
 // for the transition pass as in k_paths.  Everything else — the branch-free step (rt_pslot.hpp), nibble map, tables, cursors,
 // values — is k_paths'.
 //
-// Measured on the headline frame (profiles/README.md): the slots are fuller as intended — 35.0 M slot-steps at 61 % against
-// k_paths' 45.2 M at 47 %, 2.76 M passes against 3.34 M — but every slot now tracks the step axis, the re-arm block runs almost
-// every iteration at small `rmin` (or leaves slots waiting at a large one), and the loop's scalar bookkeeping doubles: 3.44 G VALU
-// + 1.28 G SALU instructions per launch against 3.58 G + 0.67 G, 5.42 ms against 5.23 ms.  k_paths stays RT_KERNEL_DEFAULT's
-// kernel; this one is selectable (RT_KERNEL_SEQ, RT_SEQ_NC=2|3) and runs the same parity tests.
+// Measured on the headline frame (profiles/README.md): the slots are fuller as intended — with three paths per lane 35.0 M
+// slot-steps at 61 % against k_paths' 45.2 M at 47 %, 2.76 M passes against 3.34 M — but every slot now tracks the step axis, the
+// re-arm block runs almost every iteration at small `rmin` (or leaves slots waiting at a large one), and the loop's scalar
+// bookkeeping doubles: 3.44 G VALU + 1.28 G SALU instructions per launch against 3.58 G + 0.67 G, 5.42 ms against 5.23 ms
+// (one look at the contexts per step).  With three steps per look: 5.13 ms with three paths per lane (128 VGPRs: the
+// scheduler has no room left), **5.01 ms with two** (106 VGPRs) — level with k_paths' 5.01 ms, not ahead.  k_paths stays
+// RT_KERNEL_DEFAULT's kernel; this one is selectable (RT_KERNEL_SEQ, RT_SEQ_NC=2|3, default 2) and runs the same parity tests.
 //
 // Restrictions as k_paths: RT_FLAG_CACHE_PRIMARY, lr = (0,0,0), region 256.
 #include <hip/hip_runtime.h>
@@ -22,6 +24,10 @@
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
 #include "rt_pslot.hpp"
+
+#ifndef RT_SEQ_STEPS_PER_CHECK
+#define RT_SEQ_STEPS_PER_CHECK 3   // step iterations between two looks at the waiting / parked contexts (4: 5.04 ms, 6: 5.24 ms)
+#endif
 
 namespace rtd {
 using namespace pslot;
@@ -348,6 +354,8 @@ __global__ __launch_bounds__(1024) void k_seq(Scene sc, Frame f, Planes pl, Pers
             if (live == 0ull) { leave = best == 0u; break; }
             if (COUNT) { d_iters++; d_live += nlive; }
             // ---- one step of all slots: nibble reads, then byte loads, then the arithmetic ----
+#pragma unroll
+            for (int rep = 0; rep < RT_SEQ_STEPS_PER_CHECK; rep++) {
             uint32_t v[NC], w[NC], t[NC], b[NC];
             bool g[NC];
 #pragma unroll
@@ -362,6 +370,7 @@ __global__ __launch_bounds__(1024) void k_seq(Scene sc, Frame f, Planes pl, Pers
             for (int c = 0; c < NC; c++) {
                 t[c] = g[c] ? b[c] : t[c];
                 p_advance<false, 2>(C[c].r, t[c], true, swz);
+            }
             }
         }
         if (leave) break;   // nothing in flight, nothing waiting, nothing parked, no paths left

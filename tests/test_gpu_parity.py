@@ -760,3 +760,18 @@ def test_rt_bench_binary_runs_and_reports_metrics(native_built):
     assert lines["plain"]["depth_plane_checksum"] == 0
     assert lines["gather"]["depth_plane_checksum"] == lines["overlap"]["depth_plane_checksum"] > 0
     assert lines["gather"]["rays_per_frame"] == lines["plain"]["rays_per_frame"]
+
+
+@pytest.mark.parametrize("nc", ["2", "3"])
+def test_seq_kernel_with_two_and_three_paths_per_lane(procedural_region, blue_noise, nc, monkeypatch):
+    """RT_KERNEL_SEQ carries RT_SEQ_NC paths per lane (one ray slot each): both instantiations, planes and the exact counters of
+    the cached-primary frame, at depths on both sides of the LDS / global albedo-stack boundary."""
+    monkeypatch.setenv("RT_SEQ_NC", nc)
+    mats, mine = procedural_region
+    u = _uniforms(seed=31)
+    for W, H, spp, depth in ((104, 56, 3, 4), (72, 40, 2, 7)):
+        cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+        gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, abi.RT_KERNEL_SEQ,
+                               flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS)
+        _compare(gpu, cpu)
+        assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
