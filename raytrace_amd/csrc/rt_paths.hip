@@ -21,7 +21,9 @@
 // level" — were built and measured: 6.08 ms against 5.3 ms for the combined pass; twice as many passes, each with its own
 // chain of dependent loads, cost more than the better-filled halves saved.)
 //
-// Restrictions (rt_api.hip dispatches everything else to k_persist): RT_FLAG_CACHE_PRIMARY, lr = (0,0,0), region 256.
+// Restrictions (rt_api.hip dispatches everything else to k_persist): RT_FLAG_CACHE_PRIMARY, lr = (0,0,0).  Regions 512 and
+// 1024 (LOGR 9, 10) use larger swizzle tables (2 R entries per axis) and derive the nibble-map entry from the brick coordinates;
+// their tables leave no LDS for the albedo stack, which then lives in global memory (STK = 1).
 #include <hip/hip_runtime.h>
 
 #include "rt_device.hpp"
@@ -40,10 +42,13 @@ using namespace pslot;
 // STK: where the albedo stack of the two paths lives — 0 = LDS (depth <= 4: three levels per path: the 24 KiB the nibble map
 // and the tables leave hold exactly 2 x 3 rows), 1 = global memory.  (Deeper frames with the first three levels in LDS and the
 // rest in global memory were measured on the 4K spp-256 depth-8 frame: 8.63 instead of 8.51 ms per launch.)
-template <bool COUNT, int STK>
+template <bool COUNT, int STK, int LOGR>
 __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, PersistArgs a) {
+    static_assert(LOGR == 8 || STK == 1, "the larger regions' tables leave no LDS for the albedo stack");
+    constexpr int R = 1 << LOGR, LB = LOGR - 2;
+    constexpr uint32_t kTabWords = swz_bytes<LOGR>() / 4u;   // 2 R entries per axis
     __shared__ uint32_t s_coarse[kCoarseWords];
-    __shared__ __attribute__((aligned(2048))) uint32_t s_swz[3 * 512];   // swizzle tables (see p_advance)
+    __shared__ __attribute__((aligned(swz_bytes<LOGR>()))) uint32_t s_swz[3 * kTabWords];   // swizzle tables (see p_advance)
     __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
     __shared__ uint32_t s_stack[STK == 0 ? 2 : 1][STK == 0 ? 3 : 1][STK == 0 ? 1024 : 1];
     const uint32_t nwork = *a.wl_count;
@@ -54,15 +59,14 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         uint4* dst = reinterpret_cast<uint4*>(s_coarse);
         for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
         if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
-        for (uint32_t i = threadIdx.x; i < 3u * 512u; i += 1024u) {   // entry 256 = the wrap to texel 0; 257.. are never used
-            const uint32_t ax = i >> 9, v = i & 255u;
-            s_swz[i] = ((v & 3u) << (2u * ax)) | ((v >> 2) << (6u + 6u * ax));
+        for (uint32_t i = threadIdx.x; i < 3u * kTabWords; i += 1024u) {   // entry R = the wrap to texel 0; R+1.. are never used
+            const uint32_t ax = i / kTabWords, v = i & (uint32_t)(R - 1);
+            s_swz[i] = ((v & 3u) << (2u * ax)) | ((v >> 2) << (6u + (uint32_t)LB * ax));
         }
     }
     __syncthreads();
 
-    constexpr float half = 128.0f;
-    constexpr int R = 256;
+    constexpr float half = (float)(R / 2);
     const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
     const uint32_t swz = (uint32_t)(uintptr_t)(lds_u32*)s_swz;   // LDS byte address of the tables
     const uint32_t lane = threadIdx.x & 63u;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     const uint32_t D = (uint32_t)f.depth;
     const uint32_t stack_levels = D > 1u ? D - 1u : 1u;
     // minefield bytes as a buffer: a lane that needs no byte passes an out-of-range offset (no access, returns 0)
-    const auto mine_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sc.mine), (short)0, R * R * R, 0x00020000);
+    const auto mine_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sc.mine), (short)0, 1 << (3 * LOGR), 0x00020000);
 
     PSlot SA, FA, SB, FB;
     SA.px = SA.py = SA.pz = SA.ndx = SA.ndy = SA.lx = SA.ly = SA.lz = 0.0f; SA.ndz = -1.0f;
@@ -96,7 +100,9 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     // minefield value of a slot's current texel (nibble map, byte array behind it), outside the step loop
     auto lookup = [&](const PSlot& r) -> uint32_t {
         const uint32_t vox = ps_vox(r);
-        uint32_t st = (s_nib[vox >> 7] >> ((vox >> 4) & 4u)) & 15u;
+        uint32_t nb, nsh;
+        ps_nibble_of<LOGR>(vox, &nb, &nsh);
+        uint32_t st = (s_nib[nb] >> nsh) & 15u;
         if (st == kNibMixed) st = sc.mine[vox];
         return st;
     };
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         if (__builtin_expect(__ballot(outside) != 0ull, 0)) {   // rare (origin outside the region): see p_advance
             uint32_t st = 0;
             if (outside) st = lookup(r);
-            p_advance<true, 1>(r, st, outside, swz);
+            p_advance<true, 1, LOGR>(r, st, outside, swz);
         }
     };
 
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         if (COUNT) { c_noise++; c_shadow++; c_dif++; }
         int ix, iy, iz;
         const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
-        const uint32_t tx = s_swz[ix], ty = s_swz[512 + iy], tz = s_swz[1024 + iz];
+        const uint32_t tx = s_swz[ix], ty = s_swz[kTabWords + iy], tz = s_swz[2u * kTabWords + iz];
         // F's direction registers still hold the entry of the path's previous level; it repeats whenever the next surface has
         // the same face
         const uint32_t se = P.ent & 0xFFFFu;
@@ -300,9 +306,11 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
 #pragma unroll
             for (int rep = 0; rep < RT_PATHS_STEPS_PER_CHECK; rep++) {
             const uint32_t v0 = ps_vox(SA), v1 = ps_vox(FA), v2 = ps_vox(SB), v3_ = ps_vox(FB);
-            const uint32_t w0 = s_nib[v0 >> 7], w1 = s_nib[v1 >> 7], w2 = s_nib[v2 >> 7], w3 = s_nib[v3_ >> 7];
-            uint32_t t0 = __builtin_amdgcn_ubfe(w0, (v0 >> 4) & 4u, 4u), t1 = __builtin_amdgcn_ubfe(w1, (v1 >> 4) & 4u, 4u),
-                     t2 = __builtin_amdgcn_ubfe(w2, (v2 >> 4) & 4u, 4u), t3 = __builtin_amdgcn_ubfe(w3, (v3_ >> 4) & 4u, 4u);
+            uint32_t n0, n1, n2, n3, h0, h1, h2, h3;     // nibble-map byte and nibble offset of each slot's texel
+            ps_nibble_of<LOGR>(v0, &n0, &h0); ps_nibble_of<LOGR>(v1, &n1, &h1); ps_nibble_of<LOGR>(v2, &n2, &h2); ps_nibble_of<LOGR>(v3_, &n3, &h3);
+            const uint32_t w0 = s_nib[n0], w1 = s_nib[n1], w2 = s_nib[n2], w3 = s_nib[n3];
+            uint32_t t0 = __builtin_amdgcn_ubfe(w0, h0, 4u), t1 = __builtin_amdgcn_ubfe(w1, h1, 4u),
+                     t2 = __builtin_amdgcn_ubfe(w2, h2, 4u), t3 = __builtin_amdgcn_ubfe(w3, h3, 4u);
             const bool g0 = ps_running(SA.nk) && t0 == kNibMixed, g1 = ps_running(FA.nk) && t1 == kNibMixed,
                        g2 = ps_running(SB.nk) && t2 == kNibMixed, g3 = ps_running(FB.nk) && t3 == kNibMixed;
             const uint32_t b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
@@ -310,10 +318,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             const uint32_t b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
             const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g3 ? v3_ : 0xFFFFFFFFu, 0, 0);
             t0 = g0 ? b0 : t0; t1 = g1 ? b1 : t1; t2 = g2 ? b2 : t2; t3 = g3 ? b3 : t3;
-            p_advance<false, 0>(SA, t0, true, swz);
-            p_advance<false, 1>(FA, t1, true, swz);
-            p_advance<false, 0>(SB, t2, true, swz);
-            p_advance<false, 1>(FB, t3, true, swz);
+            p_advance<false, 0, LOGR>(SA, t0, true, swz);
+            p_advance<false, 1, LOGR>(FA, t1, true, swz);
+            p_advance<false, 0, LOGR>(SB, t2, true, swz);
+            p_advance<false, 1, LOGR>(FB, t3, true, swz);
             }
         }
         if ((parkA | parkB) == 0ull) break;   // nothing in flight, nothing parked, no paths left
@@ -336,16 +344,19 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
 
 hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nworkgroups,
                         hipStream_t st) {
-    if (f.logr != 8 || f.lr_zero == 0) return hipErrorInvalidValue;
+    if (f.logr < 8 || f.logr > 10 || f.lr_zero == 0) return hipErrorInvalidValue;
     const dim3 grid(nworkgroups), block(1024);
-    const bool lds_stack = f.depth <= 4;
-    if (lds_stack) {
-        if (count) hipLaunchKernelGGL((k_paths<true, 0>), grid, block, 0, st, sc, f, pl, a);
-        else hipLaunchKernelGGL((k_paths<false, 0>), grid, block, 0, st, sc, f, pl, a);
+    const bool lds_stack = f.depth <= 4 && f.logr == 8;   // the larger regions' swizzle tables take the LDS the stack would need
+#define RT_LAUNCH_PATHS(C, S, L) hipLaunchKernelGGL((k_paths<C, S, L>), grid, block, 0, st, sc, f, pl, a)
+    if (f.logr == 8) {
+        if (lds_stack) { if (count) RT_LAUNCH_PATHS(true, 0, 8); else RT_LAUNCH_PATHS(false, 0, 8); }
+        else { if (count) RT_LAUNCH_PATHS(true, 1, 8); else RT_LAUNCH_PATHS(false, 1, 8); }
+    } else if (f.logr == 9) {
+        if (count) RT_LAUNCH_PATHS(true, 1, 9); else RT_LAUNCH_PATHS(false, 1, 9);
     } else {
-        if (count) hipLaunchKernelGGL((k_paths<true, 1>), grid, block, 0, st, sc, f, pl, a);
-        else hipLaunchKernelGGL((k_paths<false, 1>), grid, block, 0, st, sc, f, pl, a);
+        if (count) RT_LAUNCH_PATHS(true, 1, 10); else RT_LAUNCH_PATHS(false, 1, 10);
     }
+#undef RT_LAUNCH_PATHS
     return hipGetLastError();
 }
 

@@ -1,4 +1,6 @@
-// rt_persist.hip — the production kernels of the ray-trace path.
+// rt_persist.hip — the primary prepass, the direction tables, the ordered accumulation, and round 1's path kernels
+// (k_persist, k_persist2).  The default path kernel of big launches is k_paths (rt_paths.hip); k_persist runs the small ones,
+// frames with lr != 0 and frames without the primary cache.
 //
 //   k_primary2 : primary prepass.  One 1024-thread workgroup per CU, nibble map of the scene in LDS; a wave walks whole
 //                8x8 tiles (lane = pixel, so the wave's rays are coherent): primary ray, the five primary-only G-buffer
@@ -11,12 +13,12 @@
 //                which it walks together.  All lanes run the same DDA step loop.  A lane whose rays have ended parks;
 //                when `threshold` lanes of the wave are parked (__ballot) the wave runs ONE transition pass for all of
 //                them — consume the results, shade, start the next level (directions come from tables), or finish
-//                the path and pull the next one from the wave's 512-path chunk of the global cursor (one atomicAdd per
+//                the path and pull the next one from the wave's 128-path chunk of its XCD group's cursor (one atomicAdd per
 //                chunk, paths dealt out ballot-ranked) — so shading runs on a well-filled wave and the step loop on
 //                compacted work.  Per path one 16-byte light record goes to HBM; k_accumulate_paths adds a pixel's
 //                samples in order.
 //   k_persist2 : the same machinery regrouped — a lane carries two paths, each walking its level's shadow ray and then
-//                its diffuse ray in one ray slot (rt_dda.hpp); the kernel RT_KERNEL_DEFAULT picks for large frames.
+//                its diffuse ray in one ray slot (rt_dda.hpp); selectable (RT_KERNEL_PERSISTENT2), never the default.
 //
 // The primary ray does not depend on the seed (raytrace.comp:306-320 reads no noise), so with RT_FLAG_CACHE_PRIMARY
 // it is traced once per pixel (prepass) and every sample starts at its first shadow ray.  Without the flag the path

@@ -14,7 +14,9 @@ namespace pslot {
 // A ray in flight has 1 <= nk <= 2048; nk == 0 is a ray at the loop limit (its next iteration ends it either way).
 enum : uint32_t { K_END = 1u << 16, K_AIR = 1u << 17, K_DEAD = 1u << 18 };
 constexpr uint32_t kFreshInvalid = 1u << 24;   // counting builds: the ray's first texel was outside the texture
-constexpr uint32_t kSwzBytes = 2048;           // one swizzle table: 512 entries (0..256 used; an index is masked, never clamped)
+// one swizzle table of a 2^LOGR region: 2 R entries (0..R used, R = the wrap to texel 0; an index is masked, never clamped)
+template <int LOGR> constexpr uint32_t swz_bytes() { return 8u << LOGR; }
+constexpr uint32_t kSwzBytes = swz_bytes<8>();
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
@@ -26,6 +28,15 @@ struct PSlot {
     uint32_t sx, sy, sz, nk, axis;
 };
 __device__ __forceinline__ uint32_t ps_vox(const PSlot& r) { return r.sx | r.sy | r.sz; }
+// nibble-map entry of a swizzled voxel index: byte address in the map and bit offset (0 or 4) of the nibble.  At R = 256 a coarse
+// cube IS the 4^3 brick (entry = vox >> 6); larger regions take the top six bits of each brick coordinate.
+template <int LOGR>
+__device__ __forceinline__ void ps_nibble_of(uint32_t vox, uint32_t* byte, uint32_t* shift) {
+    if (LOGR == 8) { *byte = vox >> 7; *shift = (vox >> 4) & 4u; return; }
+    constexpr int LB = LOGR - 2, SUB = LOGR - 8;
+    const uint32_t c = ((vox >> (6 + SUB)) & 63u) | ((vox >> (LB + SUB)) & (63u << 6)) | ((vox >> (2 * LB + SUB - 6)) & (63u << 12));
+    *byte = c >> 1; *shift = (c & 1u) << 2;
+}
 __device__ __forceinline__ uint32_t ps_axis_of_code(uint32_t code) { return (code & 2u) ? ((code & 1u) ? 0u : 1u) : 2u; }   // p_advance<.., 2>
 __device__ __forceinline__ bool ps_running(uint32_t nk) { return nk - 1u < (uint32_t)RT_TRACE_LIMIT; }   // 1 <= nk <= 2048
 
@@ -46,9 +57,9 @@ __device__ __forceinline__ uint32_t u_bits(float f) { return __builtin_bit_cast(
 // swz = LDS byte address of the three swizzle tables (2 KiB aligned).
 // AXIS: 0 = the slot's axis word is not maintained (shadow rays), 1 = axis of the last step (0, 1, 2), 2 = the same as a
 // two-bit code built with integer subtractions instead of compares and selects (ps_axis_of_code decodes it).
-template <bool GENERIC_Q, int AXIS>
+template <bool GENERIC_Q, int AXIS, int LOGR = 8>
 __device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, uint32_t swz) {
-    constexpr float half = 128.0f;
+    constexpr float half = (float)(1 << (LOGR - 1));
     const uint32_t nk = r.nk;
     // in flight and below the loop limit (:109), on a value > 0 (:146): the ray moves.  Otherwise it has ended (or does so now:
     // hit, limit, or a fresh ray on a 0 — the pass tells them apart).
@@ -93,11 +104,13 @@ __device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, ui
     // (int)(p + 128), 256 = the wrap to texel 0.  4 * (p + 128) is fma(p, 4, 512) bit for bit (scaling by 4 commutes with the
     // rounding), its integer part with the low two bits masked is the byte offset of table entry (int)(p + 128) — and the mask
     // keeps the index of a ray that left the region (or of a lane with garbage) inside the 512-entry table.
-    const uint32_t ix = (uint32_t)(int)__builtin_fmaf(r.px, 4.0f, 512.0f), iy = (uint32_t)(int)__builtin_fmaf(r.py, 4.0f, 512.0f),
-                   iz = (uint32_t)(int)__builtin_fmaf(r.pz, 4.0f, 512.0f);
-    r.sx = *(lds_u32*)(uintptr_t)((ix & 0x7FCu) | swz);
-    r.sy = *(lds_u32*)(uintptr_t)((iy & 0x7FCu) | (swz + kSwzBytes));
-    r.sz = *(lds_u32*)(uintptr_t)((iz & 0x7FCu) | (swz + 2u * kSwzBytes));
+    constexpr float four_half = 4.0f * half;
+    constexpr uint32_t kMask = swz_bytes<LOGR>() - 4u, kTab = swz_bytes<LOGR>();     // R = 256: 0x7FC, 2048
+    const uint32_t ix = (uint32_t)(int)__builtin_fmaf(r.px, 4.0f, four_half), iy = (uint32_t)(int)__builtin_fmaf(r.py, 4.0f, four_half),
+                   iz = (uint32_t)(int)__builtin_fmaf(r.pz, 4.0f, four_half);
+    r.sx = *(lds_u32*)(uintptr_t)((ix & kMask) | swz);
+    r.sy = *(lds_u32*)(uintptr_t)((iy & kMask) | (swz + kTab));
+    r.sz = *(lds_u32*)(uintptr_t)((iz & kMask) | (swz + 2u * kTab));
 }
 
 }  // namespace pslot

@@ -427,6 +427,7 @@ def region512(native_built):
                                           (abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_CACHE_PRIMARY),
                                           (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_COUNTERS),
                                           (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_CACHE_PRIMARY),
+                                          (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY),
                                           (abi.RT_KERNEL_MEGA, abi.RT_FLAG_COUNTERS)])
 @pytest.mark.parametrize("pose", [
     dict(origin=(-60.0, -256.0, 110.0), heading=np.pi / 2, pitch=-0.05, sun=0.0, lr=(0, 0, 0)),
@@ -467,7 +468,8 @@ def test_region_1024_matches_oracle(blue_noise, native_built):
     W, H, spp, depth = 96, 64, 2, 3
     cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth, region=1024)
     for kernel, flags in ((abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS), (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_COUNTERS),
-                          (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_CACHE_PRIMARY)):
+                          (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_CACHE_PRIMARY), (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY),
+                          (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS)):
         cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=kernel, flags=flags, region=1024)
         with render.Context(cfg) as ctx:
             ctx.upload_world(mats, mine)
@@ -478,6 +480,8 @@ def test_region_1024_matches_oracle(blue_noise, native_built):
             gcn = ctx.counters()
         if flags & abi.RT_FLAG_CACHE_PRIMARY:
             _compare(gpu, cpu)
+            if flags & abi.RT_FLAG_COUNTERS:
+                assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn, region=1024)
         else:
             _compare(gpu, cpu, gcn, ccn)
 
