@@ -6,7 +6,8 @@ import os
 from .abi import RtConfig, RtCounters, RtTiming, RtUniforms
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_AMD_PATH = os.path.join(HERE, "librt_amd.so")
+# RT_AMD_LIB: load another build of the same library (same-box A/B timing of two kernel variants, tools/ab.sh)
+LIB_AMD_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "librt_amd.so")
 LIB_HOST_PATH = os.path.join(HERE, "librt_host.so")
 
 # Every symbol include/rt_abi.h declares.

@@ -30,6 +30,13 @@
 #include "rt_kernels.hpp"
 #include "rt_pslot.hpp"
 
+#ifndef RT_PATHS_SHADOW_REPS
+// Bit r: the shadow slots step in repetition r of the step group.  A level's shadow ray is short (4.5 steps on the benchmark
+// scene against the diffuse ray's 7.9) and its slot then idles until the diffuse ray ends; stepping it in three of the four
+// repetitions removes an eighth of the loop's instructions and rarely lengthens a level.  Same-box timings (tools/abn.sh):
+// 0xF 4.97 ms, 0x7 4.91, 0x5 5.03; five steps per look with 0x17: 4.99, 0x0D: 4.92; six with 0x1B: 4.92; three with 0x3: 4.97.
+#define RT_PATHS_SHADOW_REPS 0x7
+#endif
 #ifndef RT_PATHS_STEPS_PER_CHECK
 // Step iterations between two looks at the parked-lane counts.  The look costs two v_min + two v_cmp + a dozen scalar
 // instructions; four steps per look measured 5.01 ms against 5.23 ms for one (2: 5.08, 3: 5.02, 6: 5.07 at the same threshold).
@@ -305,22 +312,35 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             // ---- one step of all four slots: nibble reads, then byte loads, then the arithmetic ----
 #pragma unroll
             for (int rep = 0; rep < RT_PATHS_STEPS_PER_CHECK; rep++) {
-            const uint32_t v0 = ps_vox(SA), v1 = ps_vox(FA), v2 = ps_vox(SB), v3_ = ps_vox(FB);
-            uint32_t n0, n1, n2, n3, h0, h1, h2, h3;     // nibble-map byte and nibble offset of each slot's texel
-            ps_nibble_of<LOGR>(v0, &n0, &h0); ps_nibble_of<LOGR>(v1, &n1, &h1); ps_nibble_of<LOGR>(v2, &n2, &h2); ps_nibble_of<LOGR>(v3_, &n3, &h3);
-            const uint32_t w0 = s_nib[n0], w1 = s_nib[n1], w2 = s_nib[n2], w3 = s_nib[n3];
-            uint32_t t0 = __builtin_amdgcn_ubfe(w0, h0, 4u), t1 = __builtin_amdgcn_ubfe(w1, h1, 4u),
-                     t2 = __builtin_amdgcn_ubfe(w2, h2, 4u), t3 = __builtin_amdgcn_ubfe(w3, h3, 4u);
-            const bool g0 = ps_running(SA.nk) && t0 == kNibMixed, g1 = ps_running(FA.nk) && t1 == kNibMixed,
-                       g2 = ps_running(SB.nk) && t2 == kNibMixed, g3 = ps_running(FB.nk) && t3 == kNibMixed;
-            const uint32_t b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
+            // compile-time (the loop is unrolled).  The larger regions' steps wait on memory, not on the VALU: every slot steps
+            // in every repetition there (1024^3 region, 4K spp-1024 depth-8 frame: 182 ms against 188 ms with 0x7)
+            const bool shadow_rep = LOGR != 8 || (RT_PATHS_SHADOW_REPS >> rep & 1) != 0;
+            const uint32_t v1 = ps_vox(FA), v3_ = ps_vox(FB);
+            uint32_t n1, n3, h1, h3;     // nibble-map byte and nibble offset of each slot's texel
+            ps_nibble_of<LOGR>(v1, &n1, &h1); ps_nibble_of<LOGR>(v3_, &n3, &h3);
+            uint32_t v0 = 0, v2 = 0, n0 = 0, n2 = 0, h0 = 0, h2 = 0, w0 = 0, w2 = 0;
+            if (shadow_rep) {
+                v0 = ps_vox(SA); v2 = ps_vox(SB);
+                ps_nibble_of<LOGR>(v0, &n0, &h0); ps_nibble_of<LOGR>(v2, &n2, &h2);
+                w0 = s_nib[n0]; w2 = s_nib[n2];
+            }
+            const uint32_t w1 = s_nib[n1], w3 = s_nib[n3];
+            uint32_t t1 = __builtin_amdgcn_ubfe(w1, h1, 4u), t3 = __builtin_amdgcn_ubfe(w3, h3, 4u);
+            const bool g1 = ps_running(FA.nk) && t1 == kNibMixed, g3 = ps_running(FB.nk) && t3 == kNibMixed;
+            uint32_t t0 = 0, t2 = 0, b0 = 0, b2 = 0;
+            bool g0 = false, g2 = false;
+            if (shadow_rep) {
+                t0 = __builtin_amdgcn_ubfe(w0, h0, 4u); t2 = __builtin_amdgcn_ubfe(w2, h2, 4u);
+                g0 = ps_running(SA.nk) && t0 == kNibMixed; g2 = ps_running(SB.nk) && t2 == kNibMixed;
+                b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
+            }
             const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g1 ? v1 : 0xFFFFFFFFu, 0, 0);
-            const uint32_t b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
+            if (shadow_rep) b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
             const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g3 ? v3_ : 0xFFFFFFFFu, 0, 0);
-            t0 = g0 ? b0 : t0; t1 = g1 ? b1 : t1; t2 = g2 ? b2 : t2; t3 = g3 ? b3 : t3;
-            p_advance<false, 0, LOGR>(SA, t0, true, swz);
+            t1 = g1 ? b1 : t1; t3 = g3 ? b3 : t3;
+            if (shadow_rep) { t0 = g0 ? b0 : t0; t2 = g2 ? b2 : t2; p_advance<false, 0, LOGR>(SA, t0, true, swz); }
             p_advance<false, 1, LOGR>(FA, t1, true, swz);
-            p_advance<false, 0, LOGR>(SB, t2, true, swz);
+            if (shadow_rep) p_advance<false, 0, LOGR>(SB, t2, true, swz);
             p_advance<false, 1, LOGR>(FB, t3, true, swz);
             }
         }
