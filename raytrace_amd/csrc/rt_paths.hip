@@ -166,83 +166,28 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         else a.stack[((size_t)c * stack_levels + j) * a.nthreads + gtid] = m;
     };
 
-    // both rays of a level (:324-330 / :336-342) from the surface point (sfx, sfy, sfz) with face id snormal: the shadow ray's
-    // direction is in S's registers for the whole path, the diffuse ray's comes from the table
-    auto begin_level = [&](PSlot& S, PSlot& F, PPath& P, float sfx, float sfy, float sfz, uint32_t snormal) {
-        if (COUNT) { c_noise++; c_shadow++; c_dif++; }
-        int ix, iy, iz;
-        const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
-        const uint32_t tx = s_swz[ix], ty = s_swz[kTabWords + iy], tz = s_swz[2u * kTabWords + iz];
-        // F's direction registers still hold the entry of the path's previous level; it repeats whenever the next surface has
-        // the same face
-        const uint32_t se = P.ent & 0xFFFFu;
-        if (snormal != P.ent >> 16) {
-            const uint32_t di = 4u * ((snormal << 16) | se);
-            const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
-            F.ndx = -d2.x; F.ndy = -d2.y; F.ndz = -d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
-            P.ent = se | snormal << 16;
-        }
-        arm(S, sfx, sfy, sfz, ok, tx, ty, tz);
-        arm(F, sfx, sfy, sfz, ok, tx, ty, tz);
-    };
-
     // =========================== transition pass of one context ============================================
+    // A wave inside its pass steps none of its rays, so the pass is written for latency: every lane's first loads — the sky
+    // entry of a path that ends in the sky, the material of a hit, worklist entry and noise bytes of a new path — go out
+    // together, whatever kind of transition the lane makes, then the direction-table entries of everyone who starts a level;
+    // each batch is waited for once.  (Loads inside the three divergent branches, as the pass was first written, made a chain
+    // of five dependent memory round trips per pass.)  A lane that has nothing to fetch reads element 0.
     auto pass = [&](PSlot& S, PSlot& F, PPath& P, const uint32_t c) {
         const bool ended = min(S.nk, F.nk) >= K_END;
         const uint32_t level = P.st >> 20;
         const bool mine = ended && level != 0u;
-        if (COUNT) { d_passf++; d_plf += (uint32_t)__popcll(__ballot(mine)); }
-        bool start = false;
-        float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
-        uint32_t snormal = 0;
-        if (mine) {
-            if (COUNT) { tally(F); tally(S); }
-            uint32_t sunbits = P.st & 0xFFFFu;
-            if (S.nk & K_AIR) sunbits |= 1u << (level - 1u);               // :326-328 / :338-340
-            const bool air = (F.nk & K_AIR) != 0u;
-            if (((F.nk | P.st) & K_AIR) != 0u) {   // sky exit or last level: the path ends
-                vec3 sky = v3(0, 0, 0);
-                if (air) {   // :331-332 / :343-345, tabulated per frame
-                    const float4 t = a.dif_lut[4u * P.ent + 3u];   // P.ent = (face << 16 | noise bytes) = the entry F walked
-                    sky = v3(t.x, t.y, t.z);
-                }
-                // L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
-                vec3 L = v3(0.0f, 0.0f, 0.0f);
-                if (sunbits >> (level - 1u) & 1u) L = vadd(L, sunlight);
-                if (air) L = vadd(L, sky);
-                for (uint32_t j = level - 1u; j >= 1u; j--) {
-                    const uint32_t pm = stack_at(c, j - 1u);
-                    vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
-                    light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
-                    vec3 acc = v3(0.0f, 0.0f, 0.0f);
-                    if (sunbits >> (j - 1u) & 1u) acc = vadd(acc, sunlight);
-                    L = vadd(acc, light2);
-                }
-                const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
-                a.pl[P.item] = make_float4(light.x, light.y, light.z, 0.0f);   // k_accumulate_paths adds a pixel's samples in order
-                P.st = PP_FINAL;
-            } else {
-                // Diffuse result.  The hit texel is the texel of the last fetch, so the material is mat[vox] (:150-154); the
-                // position gets the 0.001 face offset (:166-180).
-                const uint32_t kind = stop_kind(F);
-                const uint32_t axis = F.axis;
-                const uint32_t nrm = axis == 0u ? (F.ndx < 0.0f ? 1u : 0u) : (axis == 1u ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
-                uint32_t material = 0;
-                if (kind == 0u) material = sc.mat[ps_vox(F)];
-                float hx = F.px, hy = F.py, hz = F.pz;
-                if (kind == 2u) { hx = hy = hz = __builtin_nanf(""); }
-                const float offv = (nrm & 1u) ? -0.001f : 0.001f;
-                hx = axis == 0u ? hx + offv : hx; hy = axis == 1u ? hy + offv : hy; hz = axis == 2u ? hz + offv : hz;
-                stack_put(c, level - 1u, material);   // albedo of surface level+1
-                P.st = sunbits | (level + 1u) << 20 | (level + 1u == D ? PP_FINAL : 0u);
-                sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
-                start = true;
-            }
+        const bool fin = mine && ((F.nk | P.st) & K_AIR) != 0u;   // sky exit or last level: the path ends
+        const bool cont = mine && !fin;
+        if (COUNT) {
+            d_passf++; d_plf += (uint32_t)__popcll(__ballot(mine));
+            if (mine) { tally(F); tally(S); }
         }
-        // contexts without a path pull the next ones: the wave owns a chunk of kChunk consecutive paths of its XCD group's
-        // share (one atomicAdd per chunk) and deals them out ballot-ranked (see k_persist)
+        // contexts without a path (or whose path ends here) pull the next ones: the wave owns a chunk of kChunk consecutive paths
+        // of its XCD group's share (one atomicAdd per chunk) and deals them out ballot-ranked (see k_persist)
+        bool getnew = false;
+        uint32_t nsb = 0, nw = 0;   // (sample-in-batch, worklist slot) of the new path
         if (!exhausted) {
-            const bool wantme = ended && (P.st >> 20) == 0u;
+            const bool wantme = ended && (level == 0u || fin);
             const uint64_t want = __ballot(wantme);
             const uint32_t nwant = (uint32_t)__popcll(want);
             if (nwant) {
@@ -250,15 +195,15 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
                     for (;;) {
                         if (grp_tries == 8u) { exhausted = true; chunk_next = chunk_end = 0u; break; }
                         const uint32_t g = (home_grp + grp_tries) & 7u;
-                        const uint32_t w0 = (uint32_t)((uint64_t)nwork * g >> 3), nw = (uint32_t)((uint64_t)nwork * (g + 1u) >> 3) - w0;
-                        const uint32_t ng = nw * a.nsamples;
+                        const uint32_t w0 = (uint32_t)((uint64_t)nwork * g >> 3), gw = (uint32_t)((uint64_t)nwork * (g + 1u) >> 3) - w0;
+                        const uint32_t ng = gw * a.nsamples;
                         uint32_t base = 0;
                         if (lane == 0) base = atomicAdd(a.cursor + 32u * g, kChunk);
                         base = __builtin_amdgcn_readfirstlane(base);
                         if (base < ng) {
                             chunk_next = base; chunk_end = base + kChunk < ng ? base + kChunk : ng;
-                            chunk_w0 = w0; chunk_nw = nw;
-                            chunk_sb = base / nw; chunk_w = base - chunk_sb * nw;   // once per chunk
+                            chunk_w0 = w0; chunk_nw = gw;
+                            chunk_sb = base / gw; chunk_w = base - chunk_sb * gw;   // once per chunk
                             break;
                         }
                         grp_tries++;   // that group's share is handed out for good (its cursor only grows)
@@ -266,38 +211,103 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
                 }
                 const uint32_t take = min(nwant, chunk_end - chunk_next);
                 chunk_next += take;
-                if (wantme) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-                    if (rank < take) {
-                        // (sample-in-batch, slot) of path first+rank, stepped from the chunk's running position (no division)
-                        uint32_t sb = chunk_sb, w = chunk_w + rank;
-                        while (w >= chunk_nw) { w -= chunk_nw; sb++; }
-                        w += chunk_w0;   // worklist slot
-                        const uint32_t info = a.pinfo[w];
-                        sfx = a.phx[w]; sfy = a.phy[w]; sfz = a.phz[w];
-                        snormal = info >> 28;
-                        const uint32_t wgx8 = info & 0x3FFFu, wgy8 = (info >> 14) & 0x3FFFu;
-                        P.item = sb * nwork + w;
-                        // noise_offset of this path (:298-304) and its noise_value texel (:324, :336); one integer lookup serves
-                        // every level (Q5; tests/test_math_contract.py::test_noise_value_texel_is_level_independent)
-                        const uint32_t seed = (f.seed + a.sample0 + sb) % (uint32_t)RT_NOISE_BYTES;
-                        const uint32_t by = seed / RT_NOISE_SIZE;
-                        const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
-                        const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
-                        const uint32_t se = sc.noise[ty * RT_NOISE_SIZE + tx] & 0xFFFFu;
-                        // the shadow ray's direction depends on the path's noise bytes only: one table read per path
-                        const float4 sd = a.sun_lut[2u * se], sl = a.sun_lut[2u * se + 1u];
-                        S.ndx = -sd.x; S.ndy = -sd.y; S.ndz = -sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
-                        P.ent = se | 7u << 16;
-                        P.st = 1u << 20 | (D == 1u ? PP_FINAL : 0u);
-                        start = true;
-                    }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                if (wantme && rank < take) {
+                    // (sample-in-batch, slot) of path first+rank, stepped from the chunk's running position (no division)
+                    uint32_t sb = chunk_sb, w = chunk_w + rank;
+                    while (w >= chunk_nw) { w -= chunk_nw; sb++; }
+                    nsb = sb; nw = w + chunk_w0;
+                    getnew = true;
                 }
                 chunk_w += take;
                 while (chunk_w >= chunk_nw) { chunk_w -= chunk_nw; chunk_sb++; }
             }
         }
-        if (start) begin_level(S, F, P, sfx, sfy, sfz, snormal);
+
+        // ---- first batch of loads
+        const bool air = fin && (F.nk & K_AIR) != 0u;
+        const uint32_t kind = stop_kind(F);                    // consulted for `cont` lanes only
+        const bool hit = cont && kind == 0u;
+        const float4 skyv = a.dif_lut[air ? 4u * P.ent + 3u : 0u];   // :331-332 / :343-345, tabulated per frame; P.ent = the entry F walked
+        const uint32_t matv = sc.mat[hit ? ps_vox(F) : 0u];          // the hit texel is the texel of the last fetch (:150-154)
+        const uint32_t info = a.pinfo[nw];
+        const float ox = a.phx[nw], oy = a.phy[nw], oz = a.phz[nw];
+        // noise_offset of the new path (:298-304) and its noise_value texel (:324, :336); one integer lookup serves every level
+        // (Q5; tests/test_math_contract.py::test_noise_value_texel_is_level_independent)
+        const uint32_t seed = (f.seed + a.sample0 + nsb) % (uint32_t)RT_NOISE_BYTES;
+        const uint32_t by = seed / RT_NOISE_SIZE;
+        const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
+        const uint32_t wgx8 = info & 0x3FFFu, wgy8 = (info >> 14) & 0x3FFFu;
+        const uint32_t ntx = ((nb & 0xFFu) + wgx8) & 511u, nty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
+        const uint32_t nse = sc.noise[nty * RT_NOISE_SIZE + ntx] & 0xFFFFu;   // second round trip, new paths only
+
+        // ---- a path ends: L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
+        uint32_t sunbits = P.st & 0xFFFFu;
+        if (mine && (S.nk & K_AIR)) sunbits |= 1u << (level - 1u);               // :326-328 / :338-340
+        if (fin) {
+            vec3 L = v3(0.0f, 0.0f, 0.0f);
+            if (sunbits >> (level - 1u) & 1u) L = vadd(L, sunlight);
+            if (air) L = vadd(L, v3(skyv.x, skyv.y, skyv.z));
+            for (uint32_t j = level - 1u; j >= 1u; j--) {
+                const uint32_t pm = stack_at(c, j - 1u);
+                vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
+                light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
+                vec3 acc = v3(0.0f, 0.0f, 0.0f);
+                if (sunbits >> (j - 1u) & 1u) acc = vadd(acc, sunlight);
+                L = vadd(acc, light2);
+            }
+            const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
+            a.pl[P.item] = make_float4(light.x, light.y, light.z, 0.0f);   // k_accumulate_paths adds a pixel's samples in order
+            P.st = PP_FINAL;
+        }
+        // ---- a diffuse ray hit: the next level stands on the hit point with the 0.001 face offset (:166-180)
+        bool start = false;
+        float sfx = 0, sfy = 0, sfz = 0;
+        uint32_t snormal = 0;
+        if (cont) {
+            const uint32_t axis = F.axis;
+            const uint32_t nrm = axis == 0u ? (F.ndx < 0.0f ? 1u : 0u) : (axis == 1u ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
+            float hx = F.px, hy = F.py, hz = F.pz;
+            if (kind == 2u) { hx = hy = hz = __builtin_nanf(""); }
+            const float offv = (nrm & 1u) ? -0.001f : 0.001f;
+            hx = axis == 0u ? hx + offv : hx; hy = axis == 1u ? hy + offv : hy; hz = axis == 2u ? hz + offv : hz;
+            stack_put(c, level - 1u, hit ? matv : 0u);   // albedo of surface level+1
+            P.st = sunbits | (level + 1u) << 20 | (level + 1u == D ? PP_FINAL : 0u);
+            sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
+            start = true;
+        }
+        if (getnew) {
+            sfx = ox; sfy = oy; sfz = oz;
+            snormal = info >> 28;
+            P.item = nsb * nwork + nw;
+            P.ent = nse | 7u << 16;
+            P.st = 1u << 20 | (D == 1u ? PP_FINAL : 0u);
+            start = true;
+        }
+
+        // ---- second batch: the direction tables.  The shadow ray's direction depends on the path's noise bytes only (one read per
+        // path); F's direction registers still hold the entry of the path's previous level, which repeats whenever the next
+        // surface has the same face.
+        const uint32_t se = P.ent & 0xFFFFu;
+        const bool newface = start && snormal != P.ent >> 16;
+        const uint32_t di = newface ? 4u * ((snormal << 16) | se) : 0u;
+        const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
+        const uint32_t si = getnew ? 2u * se : 0u;
+        const float4 sd = a.sun_lut[si], sl = a.sun_lut[si + 1u];
+        if (start) {
+            // both rays of the level (:324-330 / :336-342) from the surface point (sfx, sfy, sfz) with face id snormal
+            if (COUNT) { c_noise++; c_shadow++; c_dif++; }
+            int ix, iy, iz;
+            const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
+            const uint32_t tx = s_swz[ix], ty = s_swz[kTabWords + iy], tz = s_swz[2u * kTabWords + iz];
+            if (newface) {
+                F.ndx = -d2.x; F.ndy = -d2.y; F.ndz = -d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
+                P.ent = se | snormal << 16;
+            }
+            if (getnew) { S.ndx = -sd.x; S.ndy = -sd.y; S.ndz = -sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z; }
+            arm(S, sfx, sfy, sfz, ok, tx, ty, tz);
+            arm(F, sfx, sfy, sfz, ok, tx, ty, tz);
+        }
     };
 
     uint64_t idleA = 0ull, idleB = 0ull;   // lanes whose context is empty for good (no paths left)
