@@ -139,21 +139,12 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             if (kind == 2u) c_border += 1u + ((r.nk & kFreshInvalid) ? 1u : 0u);
         }
     };
-    // head of trace_ray (:83-107) from origin (rox, roy, roz) whose first texel has the table words (tx, ty, tz); ok = that
-    // texel is inside the texture.  The slot's direction registers (nd*, l*) are already set.
-    auto arm = [&](PSlot& r, float rox, float roy, float roz, bool ok, uint32_t tx, uint32_t ty, uint32_t tz) {
-        r.px = rox; r.py = roy; r.pz = roz;
-        r.sx = tx; r.sy = ty; r.sz = tz;
-        r.axis = 2u;              // :90 — a ray that ends before its first step reports the z face
-        // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
-        const bool bad = r.ndx != r.ndx || r.ndy != r.ndy || r.ndz != r.ndz || !ok;
-        r.nk = bad ? (K_DEAD | K_END | ((COUNT && !ok) ? kFreshInvalid : 0u)) : (uint32_t)RT_TRACE_LIMIT;
-        const bool outside = !bad && (rox + half < 0.0f || roy + half < 0.0f || roz + half < 0.0f);
-        if (__builtin_expect(__ballot(outside) != 0ull, 0)) {   // rare (origin outside the region): see p_advance
-            uint32_t st = 0;
-            if (outside) st = lookup(r);
-            p_advance<true, 1, LOGR>(r, st, outside, swz);
-        }
+    // the first step of a fresh ray whose origin lies outside the region (rare; GENERIC_Q in p_advance)
+    auto first_step = [&](PSlot& r, bool en) {
+        en = en && ps_running(r.nk);
+        uint32_t st = 0;
+        if (en) st = lookup(r);
+        p_advance<true, 1, LOGR>(r, st, en, swz);
     };
 
     // albedo stack of context c: packed material of surface j+2 at slot j
@@ -166,28 +157,42 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         else a.stack[((size_t)c * stack_levels + j) * a.nthreads + gtid] = m;
     };
 
-    // =========================== transition pass of one context ============================================
-    // A wave inside its pass steps none of its rays, so the pass is written for latency: every lane's first loads — the sky
-    // entry of a path that ends in the sky, the material of a hit, worklist entry and noise bytes of a new path — go out
-    // together, whatever kind of transition the lane makes, then the direction-table entries of everyone who starts a level;
-    // each batch is waited for once.  (Loads inside the three divergent branches, as the pass was first written, made a chain
-    // of five dependent memory round trips per pass.)  A lane that has nothing to fetch reads element 0.
-    auto pass = [&](PSlot& S, PSlot& F, PPath& P, const uint32_t c) {
-        const bool ended = min(S.nk, F.nk) >= K_END;
-        const uint32_t level = P.st >> 20;
-        const bool mine = ended && level != 0u;
-        const bool fin = mine && ((F.nk | P.st) & K_AIR) != 0u;   // sky exit or last level: the path ends
+    // =========================== transition pass ============================================
+    // A wave inside its pass steps none of its rays, so the pass is written for latency.  (i) ONE pass serves every lane that has
+    // a parked context, whichever of its two it is (context A if both are: B follows in the next pass): the lane's context is
+    // picked into working values on entry and written back under lane masks on exit, so the wave makes one trip through the
+    // pass's memory round trips where a pass per context kind made two.  (ii) Every lane's first loads — the sky entry of a path
+    // that ends in the sky, the material of a hit, worklist entry and noise bytes of a new path — go out together, whatever
+    // kind of transition the lane makes, then the direction-table entries of everyone who starts a level; each batch is
+    // waited for once.  (Loads inside the three divergent branches, as the pass was first written, made a chain of five
+    // dependent round trips.)  A lane that has nothing to fetch reads element 0.
+    constexpr uint32_t PP_SNAN = 1u << 19, PP_FNAN = 1u << 18;   // PPath::st: the shadow / diffuse direction in the slot registers has a NaN
+    auto pass = [&]() {
+        const bool endA = min(SA.nk, FA.nk) >= K_END, endB = min(SB.nk, FB.nk) >= K_END;
+        const bool workA = endA && !(exhausted && (PA.st >> 20) == 0u), workB = endB && !(exhausted && (PB.st >> 20) == 0u);
+        const bool act = workA || workB, useB = !workA && workB;
+        const uint32_t c = useB ? 1u : 0u;
+        // the lane's context
+        const uint32_t Snk = useB ? SB.nk : SA.nk, Fnk = useB ? FB.nk : FA.nk, Faxis = useB ? FB.axis : FA.axis;
+        const float Fpx = useB ? FB.px : FA.px, Fpy = useB ? FB.py : FA.py, Fpz = useB ? FB.pz : FA.pz;
+        const float Fdx = useB ? FB.ndx : FA.ndx, Fdy = useB ? FB.ndy : FA.ndy, Fdz = useB ? FB.ndz : FA.ndz;
+        const uint32_t Fvox = useB ? ps_vox(FB) : ps_vox(FA);
+        uint32_t Pst = useB ? PB.st : PA.st, Pitem = useB ? PB.item : PA.item, Pent = useB ? PB.ent : PA.ent;
+
+        const uint32_t level = Pst >> 20;
+        const bool mine = act && level != 0u;
+        const bool fin = mine && ((Fnk | Pst) & K_AIR) != 0u;   // sky exit or last level: the path ends
         const bool cont = mine && !fin;
         if (COUNT) {
             d_passf++; d_plf += (uint32_t)__popcll(__ballot(mine));
-            if (mine) { tally(F); tally(S); }
+            if (mine) { if (useB) { tally(FB); tally(SB); } else { tally(FA); tally(SA); } }
         }
         // contexts without a path (or whose path ends here) pull the next ones: the wave owns a chunk of kChunk consecutive paths
         // of its XCD group's share (one atomicAdd per chunk) and deals them out ballot-ranked (see k_persist)
         bool getnew = false;
         uint32_t nsb = 0, nw = 0;   // (sample-in-batch, worklist slot) of the new path
         if (!exhausted) {
-            const bool wantme = ended && (level == 0u || fin);
+            const bool wantme = act && (level == 0u || fin);
             const uint64_t want = __ballot(wantme);
             const uint32_t nwant = (uint32_t)__popcll(want);
             if (nwant) {
@@ -225,11 +230,20 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         }
 
         // ---- first batch of loads
-        const bool air = fin && (F.nk & K_AIR) != 0u;
-        const uint32_t kind = stop_kind(F);                    // consulted for `cont` lanes only
+        const bool air = fin && (Fnk & K_AIR) != 0u;
+        // How an ENDED ray that did not reach the sky stopped: 0 = hit (:146-160), 1 = loop limit (Q8: a non-air hit with
+        // material 0), 2 = special (Q12: fresh ray on a 0, NaN direction, first texel outside the texture: NaN position,
+        // material 0).  The limit case needs the value of the ray's texel once more — practically never taken.
+        uint32_t kind = ((Fnk & K_DEAD) != 0u || (Fnk & 0xFFFFu) == (uint32_t)RT_TRACE_LIMIT) ? 2u : 0u;
+        {
+            const bool at_limit = cont && kind == 0u && (Fnk & 0xFFFFu) == 0u;
+            if (__builtin_expect(__ballot(at_limit) != 0ull, 0)) {
+                if (at_limit && (useB ? lookup(FB) : lookup(FA)) != 0u) kind = 1u;
+            }
+        }
         const bool hit = cont && kind == 0u;
-        const float4 skyv = a.dif_lut[air ? 4u * P.ent + 3u : 0u];   // :331-332 / :343-345, tabulated per frame; P.ent = the entry F walked
-        const uint32_t matv = sc.mat[hit ? ps_vox(F) : 0u];          // the hit texel is the texel of the last fetch (:150-154)
+        const float4 skyv = a.dif_lut[air ? 4u * Pent + 3u : 0u];   // :331-332 / :343-345, tabulated per frame; Pent = the entry F walked
+        const uint32_t matv = sc.mat[hit ? Fvox : 0u];              // the hit texel is the texel of the last fetch (:150-154)
         const uint32_t info = a.pinfo[nw];
         const float ox = a.phx[nw], oy = a.phy[nw], oz = a.phz[nw];
         // noise_offset of the new path (:298-304) and its noise_value texel (:324, :336); one integer lookup serves every level
@@ -242,8 +256,8 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         const uint32_t nse = sc.noise[nty * RT_NOISE_SIZE + ntx] & 0xFFFFu;   // second round trip, new paths only
 
         // ---- a path ends: L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
-        uint32_t sunbits = P.st & 0xFFFFu;
-        if (mine && (S.nk & K_AIR)) sunbits |= 1u << (level - 1u);               // :326-328 / :338-340
+        uint32_t sunbits = Pst & 0xFFFFu;
+        if (mine && (Snk & K_AIR)) sunbits |= 1u << (level - 1u);               // :326-328 / :338-340
         if (fin) {
             vec3 L = v3(0.0f, 0.0f, 0.0f);
             if (sunbits >> (level - 1u) & 1u) L = vadd(L, sunlight);
@@ -257,67 +271,97 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
                 L = vadd(acc, light2);
             }
             const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
-            a.pl[P.item] = make_float4(light.x, light.y, light.z, 0.0f);   // k_accumulate_paths adds a pixel's samples in order
-            P.st = PP_FINAL;
+            a.pl[Pitem] = make_float4(light.x, light.y, light.z, 0.0f);   // k_accumulate_paths adds a pixel's samples in order
+            Pst = PP_FINAL;
         }
         // ---- a diffuse ray hit: the next level stands on the hit point with the 0.001 face offset (:166-180)
         bool start = false;
         float sfx = 0, sfy = 0, sfz = 0;
         uint32_t snormal = 0;
         if (cont) {
-            const uint32_t axis = F.axis;
-            const uint32_t nrm = axis == 0u ? (F.ndx < 0.0f ? 1u : 0u) : (axis == 1u ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
-            float hx = F.px, hy = F.py, hz = F.pz;
+            const uint32_t nrm = Faxis == 0u ? (Fdx < 0.0f ? 1u : 0u) : (Faxis == 1u ? (Fdy < 0.0f ? 3u : 2u) : (Fdz < 0.0f ? 5u : 4u));
+            float hx = Fpx, hy = Fpy, hz = Fpz;
             if (kind == 2u) { hx = hy = hz = __builtin_nanf(""); }
             const float offv = (nrm & 1u) ? -0.001f : 0.001f;
-            hx = axis == 0u ? hx + offv : hx; hy = axis == 1u ? hy + offv : hy; hz = axis == 2u ? hz + offv : hz;
+            hx = Faxis == 0u ? hx + offv : hx; hy = Faxis == 1u ? hy + offv : hy; hz = Faxis == 2u ? hz + offv : hz;
             stack_put(c, level - 1u, hit ? matv : 0u);   // albedo of surface level+1
-            P.st = sunbits | (level + 1u) << 20 | (level + 1u == D ? PP_FINAL : 0u);
+            Pst = sunbits | (Pst & (PP_SNAN | PP_FNAN)) | (level + 1u) << 20 | (level + 1u == D ? PP_FINAL : 0u);
             sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
             start = true;
         }
         if (getnew) {
             sfx = ox; sfy = oy; sfz = oz;
             snormal = info >> 28;
-            P.item = nsb * nwork + nw;
-            P.ent = nse | 7u << 16;
-            P.st = 1u << 20 | (D == 1u ? PP_FINAL : 0u);
+            Pitem = nsb * nwork + nw;
+            Pent = nse | 7u << 16;
+            Pst = 1u << 20 | (D == 1u ? PP_FINAL : 0u);
             start = true;
         }
 
         // ---- second batch: the direction tables.  The shadow ray's direction depends on the path's noise bytes only (one read per
         // path); F's direction registers still hold the entry of the path's previous level, which repeats whenever the next
         // surface has the same face.
-        const uint32_t se = P.ent & 0xFFFFu;
-        const bool newface = start && snormal != P.ent >> 16;
+        const uint32_t se = Pent & 0xFFFFu;
+        const bool newface = start && snormal != Pent >> 16;
         const uint32_t di = newface ? 4u * ((snormal << 16) | se) : 0u;
         const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
         const uint32_t si = getnew ? 2u * se : 0u;
         const float4 sd = a.sun_lut[si], sl = a.sun_lut[si + 1u];
-        if (start) {
-            // both rays of the level (:324-330 / :336-342) from the surface point (sfx, sfy, sfz) with face id snormal
-            if (COUNT) { c_noise++; c_shadow++; c_dif++; }
-            int ix, iy, iz;
-            const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
-            const uint32_t tx = s_swz[ix], ty = s_swz[kTabWords + iy], tz = s_swz[2u * kTabWords + iz];
-            if (newface) {
-                F.ndx = -d2.x; F.ndy = -d2.y; F.ndz = -d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
-                P.ent = se | snormal << 16;
-            }
-            if (getnew) { S.ndx = -sd.x; S.ndy = -sd.y; S.ndz = -sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z; }
-            arm(S, sfx, sfy, sfz, ok, tx, ty, tz);
-            arm(F, sfx, sfy, sfz, ok, tx, ty, tz);
+        // both rays of the level (:324-330 / :336-342) from the surface point (sfx, sfy, sfz) with face id snormal: head of
+        // trace_ray (:83-107)
+        if (COUNT && start) { c_noise++; c_shadow++; c_dif++; }
+        int ix, iy, iz;
+        const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
+        const uint32_t tx = s_swz[ix], ty = s_swz[kTabWords + iy], tz = s_swz[2u * kTabWords + iz];
+        if (newface) {
+            Pent = se | snormal << 16;
+            Pst = (Pst & ~PP_FNAN) | ((d2.x != d2.x || d2.y != d2.y || d2.z != d2.z) ? PP_FNAN : 0u);
         }
+        if (getnew) Pst |= (sd.x != sd.x || sd.y != sd.y || sd.z != sd.z) ? PP_SNAN : 0u;
+        // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
+        const uint32_t dead = K_DEAD | K_END | ((COUNT && !ok) ? kFreshInvalid : 0u);
+        const uint32_t nkS = ((Pst & PP_SNAN) || !ok) ? dead : (uint32_t)RT_TRACE_LIMIT;
+        const uint32_t nkF = ((Pst & PP_FNAN) || !ok) ? dead : (uint32_t)RT_TRACE_LIMIT;
+        const bool outside = start && ok && (sfx + half < 0.0f || sfy + half < 0.0f || sfz + half < 0.0f);
+
+        // the two fresh rays as they enter the step loop
+        PSlot TS, TF;
+        TS.px = sfx; TS.py = sfy; TS.pz = sfz; TS.sx = tx; TS.sy = ty; TS.sz = tz; TS.nk = nkS; TS.axis = 2u;
+        TF = TS; TF.nk = nkF;     // axis 2: a ray that ends before its first step reports the z face (:90)
+        if (__builtin_expect(__ballot(outside) != 0ull, 0)) {   // rare: the level's origin lies outside the region
+            TS.ndx = getnew ? -sd.x : (useB ? SB.ndx : SA.ndx); TS.ndy = getnew ? -sd.y : (useB ? SB.ndy : SA.ndy);
+            TS.ndz = getnew ? -sd.z : (useB ? SB.ndz : SA.ndz);
+            TS.lx = getnew ? sl.x : (useB ? SB.lx : SA.lx); TS.ly = getnew ? sl.y : (useB ? SB.ly : SA.ly); TS.lz = getnew ? sl.z : (useB ? SB.lz : SA.lz);
+            TF.ndx = newface ? -d2.x : Fdx; TF.ndy = newface ? -d2.y : Fdy; TF.ndz = newface ? -d2.z : Fdz;
+            TF.lx = newface ? dl.x : (useB ? FB.lx : FA.lx); TF.ly = newface ? dl.y : (useB ? FB.ly : FA.ly); TF.lz = newface ? dl.z : (useB ? FB.lz : FA.lz);
+            first_step(TS, outside); first_step(TF, outside);
+        }
+
+        // ---- write the lane's context back
+        if (useB) { PB.st = Pst; PB.item = Pitem; PB.ent = Pent; } else { PA.st = Pst; PA.item = Pitem; PA.ent = Pent; }
+        if (start && !useB) {
+            SA.px = TS.px; SA.py = TS.py; SA.pz = TS.pz; SA.sx = TS.sx; SA.sy = TS.sy; SA.sz = TS.sz; SA.nk = TS.nk;
+            FA.px = TF.px; FA.py = TF.py; FA.pz = TF.pz; FA.sx = TF.sx; FA.sy = TF.sy; FA.sz = TF.sz; FA.nk = TF.nk; FA.axis = TF.axis;
+        }
+        if (start && useB) {
+            SB.px = TS.px; SB.py = TS.py; SB.pz = TS.pz; SB.sx = TS.sx; SB.sy = TS.sy; SB.sz = TS.sz; SB.nk = TS.nk;
+            FB.px = TF.px; FB.py = TF.py; FB.pz = TF.pz; FB.sx = TF.sx; FB.sy = TF.sy; FB.sz = TF.sz; FB.nk = TF.nk; FB.axis = TF.axis;
+        }
+        if (newface && !useB) { FA.ndx = -d2.x; FA.ndy = -d2.y; FA.ndz = -d2.z; FA.lx = dl.x; FA.ly = dl.y; FA.lz = dl.z; }
+        if (newface && useB) { FB.ndx = -d2.x; FB.ndy = -d2.y; FB.ndz = -d2.z; FB.lx = dl.x; FB.ly = dl.y; FB.lz = dl.z; }
+        if (getnew && !useB) { SA.ndx = -sd.x; SA.ndy = -sd.y; SA.ndz = -sd.z; SA.lx = sl.x; SA.ly = sl.y; SA.lz = sl.z; }
+        if (getnew && useB) { SB.ndx = -sd.x; SB.ndy = -sd.y; SB.ndz = -sd.z; SB.lx = sl.x; SB.ly = sl.y; SB.lz = sl.z; }
     };
 
-    uint64_t idleA = 0ull, idleB = 0ull;   // lanes whose context is empty for good (no paths left)
     for (;;) {
-        uint64_t parkA, parkB;
+        uint64_t park;
         for (;;) {
-            // a context parks when both its rays have ended; when `threshold` lanes have one kind parked, that kind's pass runs
+            // a context parks when both its rays have ended; when `threshold` lanes have a parked context the pass runs
             const uint64_t eA = __ballot(min(SA.nk, FA.nk) >= K_END), eB = __ballot(min(SB.nk, FB.nk) >= K_END);
-            parkA = eA & ~idleA; parkB = eB & ~idleB;
-            if ((uint32_t)__popcll(parkA) >= threshold || (uint32_t)__popcll(parkB) >= threshold || (eA & eB) == ~0ull) break;
+            uint64_t idleA = 0ull, idleB = 0ull;   // lanes whose context is empty for good (no paths left)
+            if (exhausted) { idleA = __ballot((PA.st >> 20) == 0u); idleB = __ballot((PB.st >> 20) == 0u); }
+            park = (eA & ~idleA) | (eB & ~idleB);
+            if ((uint32_t)__popcll(park) >= threshold || (eA & eB) == ~0ull) break;
             if (COUNT) { d_iters++; d_live += (uint32_t)__popcll(~eA) + (uint32_t)__popcll(~eB); }
             // ---- one step of all four slots: nibble reads, then byte loads, then the arithmetic ----
 #pragma unroll
@@ -354,9 +398,8 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             p_advance<false, 1, LOGR>(FB, t3, true, swz);
             }
         }
-        if ((parkA | parkB) == 0ull) break;   // nothing in flight, nothing parked, no paths left
-        if ((uint32_t)__popcll(parkA) >= (uint32_t)__popcll(parkB)) pass(SA, FA, PA, 0u); else pass(SB, FB, PB, 1u);
-        if (exhausted) { idleA = __ballot((PA.st >> 20) == 0u); idleB = __ballot((PB.st >> 20) == 0u); }
+        if (park == 0ull) break;   // nothing in flight, nothing parked, no paths left
+        pass();
     }
     if (COUNT) {
         DevCounters* cn = a.counters;
