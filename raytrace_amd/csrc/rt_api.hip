@@ -385,8 +385,8 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= 4096) c->persist_chunk = (uint32_t)v & ~63u; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
-    if (c->persist_threshold == 0)   // measured optima (k_paths: 30 with four steps between looks at the parked lanes; its k_persist fallback shares it)
-        c->persist_threshold = c->persist_version == 2 ? 40u : (c->persist_version == 4 ? 36u : (c->persist_version == 3 ? 30u : 32u));
+    if (c->persist_threshold == 0)   // measured optima (k_paths: 32 lanes with a parked context, three steps between looks: 24 4.46 ms, 32 4.39, 36 4.39-4.41, 40 4.43, 44 4.51)
+        c->persist_threshold = c->persist_version == 2 ? 40u : (c->persist_version == 4 ? 36u : 32u);
     if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 16u;   // k_seq: waiting contexts that trigger the re-arm block
     if (c->kernel == RT_KERNEL_PERSISTENT) {
         RT_HIP_CREATE(dev_alloc(c, &c->pcursor, kCursorWords + 1));   // 8 cursor lines + the worklist count

@@ -30,17 +30,17 @@
 #include "rt_kernels.hpp"
 #include "rt_pslot.hpp"
 
-#ifndef RT_PATHS_SHADOW_REPS
-// Bit r: the shadow slots step in repetition r of the step group.  A level's shadow ray is short (4.5 steps on the benchmark
-// scene against the diffuse ray's 7.9) and its slot then idles until the diffuse ray ends; stepping it in three of the four
-// repetitions removes an eighth of the loop's instructions and rarely lengthens a level.  Same-box timings (tools/abn.sh):
-// 0xF 4.97 ms, 0x7 4.91, 0x5 5.03; five steps per look with 0x17: 4.99, 0x0D: 4.92; six with 0x1B: 4.92; three with 0x3: 4.97.
-#define RT_PATHS_SHADOW_REPS 0x7
-#endif
+// Step iterations between two looks at the parked contexts (the look costs two v_min + two v_cmp + a dozen scalar instructions),
+// and — bit r — whether the shadow slots step in repetition r of the group.  A level's shadow ray is short (4.5 steps on the
+// benchmark scene against the diffuse ray's 7.9) and its slot then idles until the diffuse ray ends; stepping it in two of three
+// repetitions removes a sixth of the loop's instructions and rarely lengthens a level.  Same-box timings (tools/abn.sh) with
+// the merged pass: 3 steps / 0x3 4.41 ms per launch, 3 / 0x7 4.53, 4 / 0x7 4.47, 4 / 0xF 4.56, 5 / 0x15 4.46, 5 / 0x0F 4.54,
+// 6 / 0x1B 4.88.
 #ifndef RT_PATHS_STEPS_PER_CHECK
-// Step iterations between two looks at the parked-lane counts.  The look costs two v_min + two v_cmp + a dozen scalar
-// instructions; four steps per look measured 5.01 ms against 5.23 ms for one (2: 5.08, 3: 5.02, 6: 5.07 at the same threshold).
-#define RT_PATHS_STEPS_PER_CHECK 4
+#define RT_PATHS_STEPS_PER_CHECK 3
+#endif
+#ifndef RT_PATHS_SHADOW_REPS
+#define RT_PATHS_SHADOW_REPS 0x3
 #endif
 
 namespace rtd {
