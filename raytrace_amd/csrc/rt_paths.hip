@@ -1,7 +1,7 @@
 // rt_paths.hip — k_paths, the path kernel RT_KERNEL_DEFAULT runs for cached-primary frames with lr = 0.
 //
 // Same work, same values as k_persist (rt_persist.hip); what differs is how much of it a wave keeps in flight and how the
-// instructions are spent (measured on gfx950: this path is VALU-issue bound — tools/ubench/valu_rate.hip):
+// instructions are spent (measured on gfx950, DESIGN.md 5: the step loop is bound by VALU issue — tools/ubench/valu_rate.hip — the transition passes by memory latency):
 //   * a lane carries TWO paths (contexts A and B), each with the level's shadow ray and diffuse ray in their own ray slots:
 //     four independent fetch chains per lane instead of two.  k_persist ran at an LDS-pinned four waves per SIMD with 75 of
 //     its 128 VGPRs and its waves parked at s_waitcnt half of their life (round-1 counters); the idle registers now hold
@@ -16,10 +16,20 @@
 //   * a ray's bookkeeping word counts DOWN from the loop limit, so "in flight and below the limit" is one compare; a ray that
 //     stops without reaching the sky is only marked ENDED — whether that was a hit, the loop limit or a fresh ray on a 0 is
 //     read off the word (and, for the limit, one more lookup) when the transition pass consumes it.
-// Transition passes work as in k_persist (parked lanes, __ballot threshold, per-XCD chunked cursors, direction tables), once
-// per context.  (Passes specialised by what the parked level needs — "end the path and pull the next" vs "start another
-// level" — were built and measured: 6.08 ms against 5.3 ms for the combined pass; twice as many passes, each with its own
-// chain of dependent loads, cost more than the better-filled halves saved.)
+//   * the shadow slots sit out one repetition in three of the step group (a level's shadow ray is the shorter one) — see
+//     RT_PATHS_SHADOW_REPS.
+// Transitions work as in k_persist (parked lanes, __ballot threshold, per-XCD chunked cursors, direction tables), but a wave in
+// its pass steps none of its rays, so the pass is built around its memory round trips rather than its instructions: one pass
+// serves every lane that has a parked context (A or B), and its loads go out in two batches whatever the lanes' transitions
+// are (see `pass`).  What was measured on the way, same box each time (tools/abn.sh): per-context passes with the loads inside
+// their divergent branches 4.92 ms per launch, loads batched 4.64, one pass for both contexts 4.43, three steps per look 4.39.
+// Built and measured without gain: passes specialised by what the parked level needs (6.08 against 5.3 ms); reserving the next
+// chunk of paths one pass ahead (4.83 against 4.64: the atomic's return sits in front of the pass's loads); the step group
+// software-pipelined by context, one context's arithmetic under the other's byte loads (4.98 against 4.65 — the loop wants its
+// four slots' accesses batched); the global-memory albedo stack of deep frames fetched as a column ahead of the sum (C4:
+// 137.7 against 123.9 ms, the registers it takes spill); nibble map and byte array biased by one so that "mixed or not" needs
+// no compare (2.5 % fewer loop instructions, 1 % slower: ended slots then keep fetching their byte); positions scaled by four
+// to share the table-index multiply (6 % fewer instructions, 1.7 % slower: more packed-math issue slots).
 //
 // Restrictions (rt_api.hip dispatches everything else to k_persist): RT_FLAG_CACHE_PRIMARY, lr = (0,0,0).  Regions 512 and
 // 1024 (LOGR 9, 10) use larger swizzle tables (2 R entries per axis) and derive the nibble-map entry from the brick coordinates;
