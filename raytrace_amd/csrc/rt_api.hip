@@ -581,11 +581,11 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 0);
                     // k_paths pays for its two contexts per lane once there is enough work to keep them filled: measured
-                    // crossover against k_persist at ~8 M paths per launch (1080p: spp 4 loses 10 %, spp 16 wins 9 %; the
-                    // reference's own 1024^2 1-spp frame: 0.31 vs 0.23 ms).  The worklist length lives on the device; the
-                    // pixel count bounds it.
-                    // (RT_KERNEL_PATHS asks for k_paths whatever the size.)
-                    const bool big = !ctx->paths_by_size || (uint64_t)ctx->npix_pad * ns >= (12ull << 20);
+                    // crossover against k_persist (tools/kernel_crossover.sh) between 4 M and 8 M paths per launch — 1080p spp 1:
+                    // 0.28 against 0.22 ms, 256^2 spp 64: 0.35 against 0.32, 1080p spp 4: 0.47 against 0.50, spp 16: 1.29 against
+                    // 1.65; the reference's own 1024^2 1-spp frame: 0.20 against 0.14.  The worklist length lives on the device;
+                    // the pixel count bounds it.  (RT_KERNEL_PATHS asks for k_paths whatever the size.)
+                    const bool big = !ctx->paths_by_size || (uint64_t)ctx->npix_pad * ns >= (6ull << 20);
                     if (ctx->persist_version == 4 && cache && f.lr_zero != 0 && f.logr == 8) {
                         ctx->last_path_kernel = RT_KERNEL_SEQ;
                         e = rtd::launch_seq(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->seq_nc, ctx->num_cus, ctx->stream);

@@ -15,7 +15,8 @@
 // re-arm block runs almost every iteration at small `rmin` (or leaves slots waiting at a large one), and the loop's scalar
 // bookkeeping doubles: 3.44 G VALU + 1.28 G SALU instructions per launch against 3.58 G + 0.67 G, 5.42 ms against 5.23 ms
 // (one look at the contexts per step).  With three steps per look: 5.13 ms with three paths per lane (128 VGPRs: the
-// scheduler has no room left), **5.01 ms with two** (106 VGPRs) — level with k_paths' 5.01 ms, not ahead.  k_paths stays
+// scheduler has no room left), **5.01 ms with two** (106 VGPRs) — level with k_paths' 5.01 ms at the time, not ahead; k_paths has
+// since reworked its transition pass around memory latency (4.39 ms, rt_paths.hip), which this kernel has not followed.  k_paths is
 // RT_KERNEL_DEFAULT's kernel; this one is selectable (RT_KERNEL_SEQ, RT_SEQ_NC=2|3, default 2) and runs the same parity tests.
 //
 // Restrictions as k_paths: RT_FLAG_CACHE_PRIMARY, lr = (0,0,0), region 256.
