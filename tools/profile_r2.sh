@@ -2,8 +2,9 @@
 # Round-2 profile set on the GPU box (rocprofv3; every --pmc set in its own pass).  Raw outputs land in gpurun_out/prof_r2/;
 # tools/pmc_to_json.py condenses them into profiles/r2_counters.json, the CSV/TXT summaries are copied to profiles/ by hand.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/prof_r2; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/prof_r2; rm -rf $OUT; mkdir -p $OUT   # NB: gpurun MERGES into the local gpurun_out/ — delete the local copy first too
 HEAD_ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
+HEAD_STATS_ARGS="--steps 10 --warmup 3 --no-cpu-baseline"   # kernel-trace pass: enough launches that cold ones do not set the average
 C5_ARGS="--region 1024 --width 3840 --height 2160 --spp 1024 --depth 8 --steps 1 --warmup 1 --no-cpu-baseline"
 C4_ARGS="--width 3840 --height 2160 --spp 256 --depth 8 --steps 2 --warmup 1 --no-cpu-baseline"
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
@@ -16,7 +17,7 @@ run() {   # tag, bench args, rocprof args
 }
 for w in head c5 c4; do
   case $w in head) A=$HEAD_ARGS;; c5) A=$C5_ARGS;; c4) A=$C4_ARGS;; esac
-  run ${w}_stats "$A" --kernel-trace --stats
+  if [ $w = head ]; then run ${w}_stats "$HEAD_STATS_ARGS" --kernel-trace --stats; else run ${w}_stats "$A" --kernel-trace --stats; fi
   run ${w}_fetch "$A" --pmc FETCH_SIZE
   run ${w}_write "$A" --pmc WRITE_SIZE
   run ${w}_tcc "$A" --pmc TCC_HIT_sum TCC_MISS_sum
