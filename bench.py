@@ -51,6 +51,10 @@ def parse_args():
     ap.set_defaults(cache_primary=True)
     ap.add_argument("--region", type=int, default=256, choices=[256, 512, 1024],
                     help="region edge: 256 = the reference; 1024 = the 5 GiB stress scene of config C5")
+    ap.add_argument("--lr", default="0,0,0",
+                    help="render offset of a scrolled region (multiples of 16 voxels, terrain_upload.rs:84-275): the scene is the "
+                         "toroidal window around it and the camera moves with it — what every frame looks like once the camera has "
+                         "travelled; region 256 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the additional 3840x2160 spp=256 depth=8 measurement")
     return ap.parse_args()
@@ -160,13 +164,19 @@ def main():
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
     noise = np.fromfile(os.path.join(ROOT, "tests", "golden", "blue_noise_512.rgba"), dtype=np.uint8)
     REGION = args.region
-    mats, mine = rt_world.generate_region(rt_world.DEFAULT_SEED, region=REGION)
+    LR = tuple(int(v) for v in args.lr.split(","))
+    if len(LR) != 3 or any(v % 16 for v in LR) or (LR != (0, 0, 0) and REGION != 256):
+        raise SystemExit("--lr takes three multiples of 16 (region 256)")
+    if LR == (0, 0, 0):
+        mats, mine = rt_world.generate_region(rt_world.DEFAULT_SEED, region=REGION)
+    else:
+        mats, mine = rt_world.toroidal_region(LR, rt_world.DEFAULT_SEED, region=REGION)
     pose = dict(render.DEFAULT_POSE)
     scale = REGION // 256            # C5 pose (-120,-512,400) = the default pose scaled with the region
-    pose["origin"] = tuple(c * scale for c in pose["origin"])
+    pose["origin"] = tuple(c * scale + o for c, o in zip(pose["origin"], LR))
 
     def uniforms(seed):
-        return render.camera_uniforms(pose["origin"], pose["heading"], pose["pitch"], pose["sun_angle"], seed=seed)
+        return render.camera_uniforms(pose["origin"], pose["heading"], pose["pitch"], pose["sun_angle"], seed=seed, lr=LR)
 
     uid_bytes = None
     if rccl:
@@ -344,7 +354,7 @@ def main():
                                    % ((W, H, SPP, D, REGION) + tuple(pose["origin"])), "kernel": rec["kernel"],
                        "rays_per_frame": int(rec["rays_total"]), "reference_equivalent_rays_per_frame": int(rec["ref_rays_total"]),
                        "algorithmic_bytes_per_frame": int(rec["balg_total"]), "parallelism": "tiles%d" % world,
-                       "primary_cache": bool(args.cache_primary), "frame_sha256_16": rec["sha"],
+                       "primary_cache": bool(args.cache_primary), "lr": list(LR), "frame_sha256_16": rec["sha"],
                        "seed": args.seed + ((args.steps + args.warmup - 1) if args.vary_seed else 0),
                        "gather": None if not dist_on else (("rt_gather_gbuffer over RCCL, " + ("overlapped with the next frame" if overlap
                                                                                               else "serial on the render stream"))

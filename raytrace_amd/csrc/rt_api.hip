@@ -589,7 +589,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                     if (ctx->persist_version == 4 && cache && f.lr_zero != 0 && f.logr == 8) {
                         ctx->last_path_kernel = RT_KERNEL_SEQ;
                         e = rtd::launch_seq(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->seq_nc, ctx->num_cus, ctx->stream);
-                    } else if (ctx->persist_version == 3 && cache && f.lr_zero != 0 && big) {
+                    } else if (ctx->persist_version == 3 && cache && big) {
                         ctx->last_path_kernel = RT_KERNEL_PATHS;
                         e = rtd::launch_paths(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->num_cus, ctx->stream);
                     } else {

@@ -31,7 +31,9 @@
 // no compare (2.5 % fewer loop instructions, 1 % slower: ended slots then keep fetching their byte); positions scaled by four
 // to share the table-index multiply (6 % fewer instructions, 1.7 % slower: more packed-math issue slots).
 //
-// Restrictions (rt_api.hip dispatches everything else to k_persist): RT_FLAG_CACHE_PRIMARY, lr = (0,0,0).  Regions 512 and
+// Restrictions (rt_api.hip dispatches everything else to k_persist): RT_FLAG_CACHE_PRIMARY.  Scrolled regions (lr != 0, terrain
+// streaming) run the LRZ = false instantiations: generic q, lr in the sky test, the shader's own mod for the texel and its border
+// case (rt_pslot.hpp) — 17 more VALU per slot and step.  Regions 512 and
 // 1024 (LOGR 9, 10) use larger swizzle tables (2 R entries per axis) and derive the nibble-map entry from the brick coordinates;
 // their tables leave no LDS for the albedo stack, which then lives in global memory (STK = 1).
 #include <hip/hip_runtime.h>
@@ -59,7 +61,7 @@ using namespace pslot;
 // STK: where the albedo stack of the two paths lives — 0 = LDS (depth <= 4: three levels per path: the 24 KiB the nibble map
 // and the tables leave hold exactly 2 x 3 rows), 1 = global memory.  (Deeper frames with the first three levels in LDS and the
 // rest in global memory were measured on the 4K spp-256 depth-8 frame: 8.63 instead of 8.51 ms per launch.)
-template <bool COUNT, int STK, int LOGR>
+template <bool COUNT, int STK, int LOGR, bool LRZ>
 __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, PersistArgs a) {
     static_assert(LOGR == 8 || STK == 1, "the larger regions' tables leave no LDS for the albedo stack");
     constexpr int R = 1 << LOGR, LB = LOGR - 2;
@@ -77,8 +79,9 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
         if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
         for (uint32_t i = threadIdx.x; i < 3u * kTabWords; i += 1024u) {   // entry R = the wrap to texel 0; R+1.. are never used
-            const uint32_t ax = i / kTabWords, v = i & (uint32_t)(R - 1);
-            s_swz[i] = ((v & 3u) << (2u * ax)) | ((v >> 2) << (6u + (uint32_t)LB * ax));
+            const uint32_t ax = i / kTabWords, e = i % kTabWords, v = e & (uint32_t)(R - 1);
+            const uint32_t word = ((v & 3u) << (2u * ax)) | ((v >> 2) << (6u + (uint32_t)LB * ax));
+            s_swz[i] = (!LRZ && e == (uint32_t)R) ? kSwzBorder : word;   // scrolled region: entry R = the border texel (p_advance)
         }
     }
     __syncthreads();
@@ -117,8 +120,9 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     // minefield value of a slot's current texel (nibble map, byte array behind it), outside the step loop
     auto lookup = [&](const PSlot& r) -> uint32_t {
         const uint32_t vox = ps_vox(r);
+        if (!LRZ && ps_border(vox)) return 0u;
         uint32_t nb, nsh;
-        ps_nibble_of<LOGR>(vox, &nb, &nsh);
+        ps_nibble_of<LOGR, LRZ>(vox, &nb, &nsh);
         uint32_t st = (s_nib[nb] >> nsh) & 15u;
         if (st == kNibMixed) st = sc.mine[vox];
         return st;
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             c_iter += kind == 2u ? 1u : (uint32_t)RT_TRACE_LIMIT - left;   // a ray that is special ends inside its first iteration
             if (kind == 1u) c_limit++; else c_hits++;
             if (kind == 2u) c_border += 1u + ((r.nk & kFreshInvalid) ? 1u : 0u);
+            else if (!LRZ && ps_border(ps_vox(r))) c_border++;   // the fetch that ended it went to the border texel
         }
     };
     // the first step of a fresh ray whose origin lies outside the region (rare; GENERIC_Q in p_advance)
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         en = en && ps_running(r.nk);
         uint32_t st = 0;
         if (en) st = lookup(r);
-        p_advance<true, 1, LOGR>(r, st, en, swz);
+        p_advance<true, 1, LOGR, LRZ>(r, st, en, swz, f.lr[0], f.lr[1], f.lr[2]);
     };
 
     // albedo stack of context c: packed material of surface j+2 at slot j
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         }
         const bool hit = cont && kind == 0u;
         const float4 skyv = a.dif_lut[air ? 4u * Pent + 3u : 0u];   // :331-332 / :343-345, tabulated per frame; Pent = the entry F walked
-        const uint32_t matv = sc.mat[hit ? Fvox : 0u];              // the hit texel is the texel of the last fetch (:150-154)
+        const uint32_t matv = sc.mat[(hit && !(!LRZ && ps_border(Fvox))) ? Fvox : 0u];   // the hit texel is the texel of the last fetch (:150-154); border: 0
         const uint32_t info = a.pinfo[nw];
         const float ox = a.phx[nw], oy = a.phy[nw], oz = a.phz[nw];
         // noise_offset of the new path (:298-304) and its noise_value texel (:324, :336); one integer lookup serves every level
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             if (kind == 2u) { hx = hy = hz = __builtin_nanf(""); }
             const float offv = (nrm & 1u) ? -0.001f : 0.001f;
             hx = Faxis == 0u ? hx + offv : hx; hy = Faxis == 1u ? hy + offv : hy; hz = Faxis == 2u ? hz + offv : hz;
-            stack_put(c, level - 1u, hit ? matv : 0u);   // albedo of surface level+1
+            stack_put(c, level - 1u, (hit && !(!LRZ && ps_border(Fvox))) ? matv : 0u);   // albedo of surface level+1
             Pst = sunbits | (Pst & (PP_SNAN | PP_FNAN)) | (level + 1u) << 20 | (level + 1u == D ? PP_FINAL : 0u);
             sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
             start = true;
@@ -332,7 +337,8 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         const uint32_t dead = K_DEAD | K_END | ((COUNT && !ok) ? kFreshInvalid : 0u);
         const uint32_t nkS = ((Pst & PP_SNAN) || !ok) ? dead : (uint32_t)RT_TRACE_LIMIT;
         const uint32_t nkF = ((Pst & PP_FNAN) || !ok) ? dead : (uint32_t)RT_TRACE_LIMIT;
-        const bool outside = start && ok && (sfx + half < 0.0f || sfy + half < 0.0f || sfz + half < 0.0f);
+        // (lr = 0 builds step with the q of in-region positions; a level whose origin lies outside takes its first step apart)
+        const bool outside = LRZ && start && ok && (sfx + half < 0.0f || sfy + half < 0.0f || sfz + half < 0.0f);
 
         // the two fresh rays as they enter the step loop
         PSlot TS, TF;
@@ -381,20 +387,24 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             const bool shadow_rep = LOGR != 8 || (RT_PATHS_SHADOW_REPS >> rep & 1) != 0;
             const uint32_t v1 = ps_vox(FA), v3_ = ps_vox(FB);
             uint32_t n1, n3, h1, h3;     // nibble-map byte and nibble offset of each slot's texel
-            ps_nibble_of<LOGR>(v1, &n1, &h1); ps_nibble_of<LOGR>(v3_, &n3, &h3);
+            ps_nibble_of<LOGR, LRZ>(v1, &n1, &h1); ps_nibble_of<LOGR, LRZ>(v3_, &n3, &h3);
             uint32_t v0 = 0, v2 = 0, n0 = 0, n2 = 0, h0 = 0, h2 = 0, w0 = 0, w2 = 0;
             if (shadow_rep) {
                 v0 = ps_vox(SA); v2 = ps_vox(SB);
-                ps_nibble_of<LOGR>(v0, &n0, &h0); ps_nibble_of<LOGR>(v2, &n2, &h2);
+                ps_nibble_of<LOGR, LRZ>(v0, &n0, &h0); ps_nibble_of<LOGR, LRZ>(v2, &n2, &h2);
                 w0 = s_nib[n0]; w2 = s_nib[n2];
             }
             const uint32_t w1 = s_nib[n1], w3 = s_nib[n3];
             uint32_t t1 = __builtin_amdgcn_ubfe(w1, h1, 4u), t3 = __builtin_amdgcn_ubfe(w3, h3, 4u);
+            if (!LRZ) {   // the border texel reads as "mixed", and its byte offset is out of the buffer's range: value 0
+                t1 |= (uint32_t)((int32_t)v1 >> 31) & 15u; t3 |= (uint32_t)((int32_t)v3_ >> 31) & 15u;
+            }
             const bool g1 = ps_running(FA.nk) && t1 == kNibMixed, g3 = ps_running(FB.nk) && t3 == kNibMixed;
             uint32_t t0 = 0, t2 = 0, b0 = 0, b2 = 0;
             bool g0 = false, g2 = false;
             if (shadow_rep) {
                 t0 = __builtin_amdgcn_ubfe(w0, h0, 4u); t2 = __builtin_amdgcn_ubfe(w2, h2, 4u);
+                if (!LRZ) { t0 |= (uint32_t)((int32_t)v0 >> 31) & 15u; t2 |= (uint32_t)((int32_t)v2 >> 31) & 15u; }
                 g0 = ps_running(SA.nk) && t0 == kNibMixed; g2 = ps_running(SB.nk) && t2 == kNibMixed;
                 b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
             }
@@ -402,10 +412,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             if (shadow_rep) b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
             const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g3 ? v3_ : 0xFFFFFFFFu, 0, 0);
             t1 = g1 ? b1 : t1; t3 = g3 ? b3 : t3;
-            if (shadow_rep) { t0 = g0 ? b0 : t0; t2 = g2 ? b2 : t2; p_advance<false, 0, LOGR>(SA, t0, true, swz); }
-            p_advance<false, 1, LOGR>(FA, t1, true, swz);
-            if (shadow_rep) p_advance<false, 0, LOGR>(SB, t2, true, swz);
-            p_advance<false, 1, LOGR>(FB, t3, true, swz);
+            if (shadow_rep) { t0 = g0 ? b0 : t0; t2 = g2 ? b2 : t2; p_advance<false, 0, LOGR, LRZ>(SA, t0, true, swz, f.lr[0], f.lr[1], f.lr[2]); }
+            p_advance<false, 1, LOGR, LRZ>(FA, t1, true, swz, f.lr[0], f.lr[1], f.lr[2]);
+            if (shadow_rep) p_advance<false, 0, LOGR, LRZ>(SB, t2, true, swz, f.lr[0], f.lr[1], f.lr[2]);
+            p_advance<false, 1, LOGR, LRZ>(FB, t3, true, swz, f.lr[0], f.lr[1], f.lr[2]);
             }
         }
         if (park == 0ull) break;   // nothing in flight, nothing parked, no paths left
@@ -427,18 +437,22 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
 
 hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nworkgroups,
                         hipStream_t st) {
-    if (f.logr < 8 || f.logr > 10 || f.lr_zero == 0) return hipErrorInvalidValue;
+    if (f.logr < 8 || f.logr > 10) return hipErrorInvalidValue;
     const dim3 grid(nworkgroups), block(1024);
-    const bool lds_stack = f.depth <= 4 && f.logr == 8;   // the larger regions' swizzle tables take the LDS the stack would need
-#define RT_LAUNCH_PATHS(C, S, L) hipLaunchKernelGGL((k_paths<C, S, L>), grid, block, 0, st, sc, f, pl, a)
+    // albedo stack: LDS for depth <= 4 at region 256 (the larger regions' swizzle tables take the LDS it would need), else global
+    const bool lds_stack = f.depth <= 4 && f.logr == 8;
+    const bool lrz = f.lr_zero != 0;   // false: a scrolled region (rt_pslot.hpp, p_advance)
+#define RT_LAUNCH_PATHS(C, S, L, Z) hipLaunchKernelGGL((k_paths<C, S, L, Z>), grid, block, 0, st, sc, f, pl, a)
+#define RT_LAUNCH_PATHS_CZ(S, L) do { if (count) { if (lrz) RT_LAUNCH_PATHS(true, S, L, true); else RT_LAUNCH_PATHS(true, S, L, false); } \
+                                      else { if (lrz) RT_LAUNCH_PATHS(false, S, L, true); else RT_LAUNCH_PATHS(false, S, L, false); } } while (0)
     if (f.logr == 8) {
-        if (lds_stack) { if (count) RT_LAUNCH_PATHS(true, 0, 8); else RT_LAUNCH_PATHS(false, 0, 8); }
-        else { if (count) RT_LAUNCH_PATHS(true, 1, 8); else RT_LAUNCH_PATHS(false, 1, 8); }
+        if (lds_stack) RT_LAUNCH_PATHS_CZ(0, 8); else RT_LAUNCH_PATHS_CZ(1, 8);
     } else if (f.logr == 9) {
-        if (count) RT_LAUNCH_PATHS(true, 1, 9); else RT_LAUNCH_PATHS(false, 1, 9);
+        RT_LAUNCH_PATHS_CZ(1, 9);
     } else {
-        if (count) RT_LAUNCH_PATHS(true, 1, 10); else RT_LAUNCH_PATHS(false, 1, 10);
+        RT_LAUNCH_PATHS_CZ(1, 10);
     }
+#undef RT_LAUNCH_PATHS_CZ
 #undef RT_LAUNCH_PATHS
     return hipGetLastError();
 }

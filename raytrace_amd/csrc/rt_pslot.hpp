@@ -17,6 +17,9 @@ constexpr uint32_t kFreshInvalid = 1u << 24;   // counting builds: the ray's fir
 // one swizzle table of a 2^LOGR region: 2 R entries (0..R used, R = the wrap to texel 0; an index is masked, never clamped)
 template <int LOGR> constexpr uint32_t swz_bytes() { return 8u << LOGR; }
 constexpr uint32_t kSwzBytes = swz_bytes<8>();
+// Scrolled regions (lr != 0): table entry R — mod(p + R/2, R) came out as R itself, the sampler's border texel, value 0
+// (Q7) — carries this flag instead of a texel's bits; it survives the OR of the three words (see p_advance, ps_border).
+constexpr uint32_t kSwzBorder = 0x80000000u;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
@@ -28,11 +31,12 @@ struct PSlot {
     uint32_t sx, sy, sz, nk, axis;
 };
 __device__ __forceinline__ uint32_t ps_vox(const PSlot& r) { return r.sx | r.sy | r.sz; }
+__device__ __forceinline__ bool ps_border(uint32_t vox) { return (vox & kSwzBorder) != 0u; }
 // nibble-map entry of a swizzled voxel index: byte address in the map and bit offset (0 or 4) of the nibble.  At R = 256 a coarse
 // cube IS the 4^3 brick (entry = vox >> 6); larger regions take the top six bits of each brick coordinate.
-template <int LOGR>
+template <int LOGR, bool LRZ = true>
 __device__ __forceinline__ void ps_nibble_of(uint32_t vox, uint32_t* byte, uint32_t* shift) {
-    if (LOGR == 8) { *byte = vox >> 7; *shift = (vox >> 4) & 4u; return; }
+    if (LOGR == 8) { *byte = LRZ ? vox >> 7 : (vox >> 7) & 0x1FFFFu; *shift = (vox >> 4) & 4u; return; }   // the mask: kSwzBorder
     constexpr int LB = LOGR - 2, SUB = LOGR - 8;
     const uint32_t c = ((vox >> (6 + SUB)) & 63u) | ((vox >> (LB + SUB)) & (63u << 6)) | ((vox >> (2 * LB + SUB - 6)) & (63u << 12));
     *byte = c >> 1; *shift = (c & 1u) << 2;
@@ -57,8 +61,11 @@ __device__ __forceinline__ uint32_t u_bits(float f) { return __builtin_bit_cast(
 // swz = LDS byte address of the three swizzle tables (2 KiB aligned).
 // AXIS: 0 = the slot's axis word is not maintained (shadow rays), 1 = axis of the last step (0, 1, 2), 2 = the same as a
 // two-bit code built with integer subtractions instead of compares and selects (ps_axis_of_code decodes it).
-template <bool GENERIC_Q, int AXIS, int LOGR = 8>
-__device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, uint32_t swz) {
+// LRZ = false: a scrolled region, lr = (lrx, lry, lrz) != 0 (terrain_upload.rs:84-275).  Positions then lie anywhere in
+// [lr - R/2, lr + R/2): q needs the generic form, the sky test its subtraction, and the texel the shader's own
+// mod(p + R/2, R) = fma(-R, floor(x / R), x) — whose one rounding can land on R itself (the border texel: kSwzBorder).
+template <bool GENERIC_Q, int AXIS, int LOGR = 8, bool LRZ = true>
+__device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, uint32_t swz, float lrx = 0.0f, float lry = 0.0f, float lrz = 0.0f) {
     constexpr float half = (float)(1 << (LOGR - 1));
     const uint32_t nk = r.nk;
     // in flight and below the loop limit (:109), on a value > 0 (:146): the ray moves.  Otherwise it has ended (or does so now:
@@ -70,6 +77,10 @@ __device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, ui
     float qx, qy, qz;                                            // (pos + 128) * muls, :94-98,119
     if (GENERIC_Q) {
         qx = r.ndx < 0.0f ? -ux : ux; qy = r.ndy < 0.0f ? -uy : uy; qz = r.ndz < 0.0f ? -uz : uz;
+    } else if (!LRZ) {   // u of either sign on every step: flip it where nd is negative (nd = -0: see rt_dda.hpp, that axis never wins)
+        qx = f_bits(u_bits(ux) ^ (u_bits(r.ndx) & 0x80000000u));
+        qy = f_bits(u_bits(uy) ^ (u_bits(r.ndy) & 0x80000000u));
+        qz = f_bits(u_bits(uz) ^ (u_bits(r.ndz) & 0x80000000u));
     } else {
         qx = f_bits((u_bits(ux) & 0x7FFFFFFFu) | (u_bits(r.ndx) & 0x80000000u));
         qy = f_bits((u_bits(uy) & 0x7FFFFFFFu) | (u_bits(r.ndy) & 0x80000000u));
@@ -97,7 +108,8 @@ __device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, ui
     r.px = __builtin_fmaf(-r.ndx, te, r.px); r.py = __builtin_fmaf(-r.ndy, te, r.py); r.pz = __builtin_fmaf(-r.ndz, te, r.pz);
     // sky test (:138-145; with lr = 0 the subtraction p - lr is the identity).  max ignores a NaN operand like the three
     // compares would.
-    const bool sky = __builtin_fmaxf(__builtin_fmaxf(rtm_abs(r.px), rtm_abs(r.py)), rtm_abs(r.pz)) >= half;
+    const bool sky = LRZ ? __builtin_fmaxf(__builtin_fmaxf(rtm_abs(r.px), rtm_abs(r.py)), rtm_abs(r.pz)) >= half
+                         : __builtin_fmaxf(__builtin_fmaxf(rtm_abs(r.px - lrx), rtm_abs(r.py - lry)), rtm_abs(r.pz - lrz)) >= half;
     const uint32_t moved = nk + (sky ? (K_AIR | K_END) - 1u : 0xFFFFFFFFu);
     r.nk = go ? moved : (nk | K_END);
     // table words of the next fetch's texel (:137): a position inside the bounds has mod(p + 128, 256) floor-identical to
@@ -106,8 +118,14 @@ __device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, ui
     // keeps the index of a ray that left the region (or of a lane with garbage) inside the 512-entry table.
     constexpr float four_half = 4.0f * half;
     constexpr uint32_t kMask = swz_bytes<LOGR>() - 4u, kTab = swz_bytes<LOGR>();     // R = 256: 0x7FC, 2048
-    const uint32_t ix = (uint32_t)(int)__builtin_fmaf(r.px, 4.0f, four_half), iy = (uint32_t)(int)__builtin_fmaf(r.py, 4.0f, four_half),
-                   iz = (uint32_t)(int)__builtin_fmaf(r.pz, 4.0f, four_half);
+    float x4 = __builtin_fmaf(r.px, 4.0f, four_half), y4 = __builtin_fmaf(r.py, 4.0f, four_half), z4 = __builtin_fmaf(r.pz, 4.0f, four_half);
+    if (!LRZ) {   // 4 * mod(p + R/2, R), bit for bit (the scaling commutes with both roundings); in [0, 4 R]
+        constexpr float four_r = 8.0f * half, inv_four_r = 1.0f / four_r;
+        x4 = __builtin_fmaf(-four_r, rtm_floor(x4 * inv_four_r), x4);
+        y4 = __builtin_fmaf(-four_r, rtm_floor(y4 * inv_four_r), y4);
+        z4 = __builtin_fmaf(-four_r, rtm_floor(z4 * inv_four_r), z4);
+    }
+    const uint32_t ix = (uint32_t)(int)x4, iy = (uint32_t)(int)y4, iz = (uint32_t)(int)z4;
     r.sx = *(lds_u32*)(uintptr_t)((ix & kMask) | swz);
     r.sy = *(lds_u32*)(uintptr_t)((iy & kMask) | (swz + kTab));
     r.sz = *(lds_u32*)(uintptr_t)((iz & kMask) | (swz + 2u * kTab));

@@ -503,6 +503,49 @@ def test_edge_shapes_match_oracle(procedural_region, blue_noise, kernel, W, H, s
                 assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
 
 
+@pytest.mark.parametrize("lr,origin,heading,pitch", [((48, 0, 32), (18.0, -128.0, 132.0), np.pi / 2, 0.0),
+                                                    ((-32, 64, -16), (-62.0, 20.0, 70.0), -0.7, -0.3),
+                                                    ((16, -48, 0), (40.0, -160.0, 30.0), 2.4, 0.4)])
+def test_scrolled_regions_run_on_k_paths(blue_noise, lr, origin, heading, pitch):
+    """Once the camera has travelled every frame has lr != 0 (terrain_upload.rs:84-275): k_paths' scrolled-region build (generic
+    q, lr in the sky test, the shader's own mod for the texel and its border case) against the oracle on the toroidal window
+    the streaming would have uploaded — planes, the cached-primary counters, and that it is k_paths that ran."""
+    mats, mine = world.toroidal_region(lr)
+    u = _uniforms(origin=origin, heading=heading, pitch=pitch, sun=0.3, seed=11, lr=lr)
+    W, H, spp, depth = 160, 96, 3, 4
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    for flags in (abi.RT_FLAG_CACHE_PRIMARY, abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS):
+        cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=abi.RT_KERNEL_PATHS, flags=flags)
+        with render.Context(cfg) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(u)
+            ctx.sync()
+            assert ctx.kernel_in_use() == abi.RT_KERNEL_PATHS
+            gpu, gcn = ctx.readback_all(), ctx.counters()
+        _compare(gpu, cpu)
+        if flags & abi.RT_FLAG_COUNTERS:
+            assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
+
+
+def test_scrolled_region_512_runs_on_k_paths(blue_noise):
+    """The same at region 512 (2 R-entry swizzle tables, nibble-map entry from the brick coordinates)."""
+    lr = (32, -16, 48)
+    mats, mine = world.toroidal_region(lr, region=512)
+    u = _uniforms(origin=(-28.0, -272.0, 250.0), heading=np.pi / 2, pitch=-0.1, sun=0.2, seed=4, lr=lr)
+    W, H, spp, depth = 96, 64, 2, 3
+    cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth, region=512)
+    cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=abi.RT_KERNEL_PATHS, flags=abi.RT_FLAG_CACHE_PRIMARY, region=512)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(u)
+        ctx.sync()
+        assert ctx.kernel_in_use() == abi.RT_KERNEL_PATHS
+        gpu = ctx.readback_all()
+    _compare(gpu, cpu)
+
+
 @pytest.mark.parametrize("kernel", PATH_KERNELS)
 def test_sample_batches_accumulate_in_order(procedural_region, blue_noise, kernel, monkeypatch):
     """spp larger than one launch holds: RT_PERSIST_BATCH forces 4 launches of 3 + 3 + 3 + 1 samples; the per-pixel sum must
