@@ -100,7 +100,7 @@ typedef enum RtKernel {
     RT_KERNEL_PERSISTENT2 = 4,/* same machinery, but a lane carries TWO paths, each walking its shadow ray then its
                                  diffuse ray in one slot (fuller waves, heavier transitions)        */
     RT_KERNEL_PATHS = 5,      /* a lane carries two paths with two ray slots each (four fetch chains in flight per lane) and
-                                 the step loop is branch-free; frames it does not cover (lr != 0, no primary cache)
+                                 the step loop is branch-free; frames it does not cover (no primary cache)
                                  run on RT_KERNEL_PERSISTENT                                                     */
     RT_KERNEL_SEQ = 6         /* branch-free like PATHS, but a lane carries three paths with ONE slot each that walks the
                                  level's shadow ray and then its diffuse ray (fuller slots); region 256 only      */
