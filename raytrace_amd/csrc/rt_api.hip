@@ -84,7 +84,7 @@ struct RtContext {
     float4* sun_lut = nullptr;
     float4* dif_lut = nullptr;
     float4* pacc = nullptr;
-    float4* ppl = nullptr;
+    rtd::PathLight* ppl = nullptr;
     uint32_t persist_batch = 1;
     uint32_t persist_chunk = 0;   // RT_PERSIST_CHUNK: paths per cursor atomic (multiple of 64); 0 = automatic
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default

@@ -56,6 +56,9 @@ struct PrimaryArgs {
     DevCounters* counters;
 };
 // k_persist (rt_persist.hip): persistent path kernel.  Work item r = sample_in_batch * nwork + w.
+// light of one path, summed per pixel in sample order by k_accumulate_paths (12 bytes: the records are the path kernels' whole
+// write traffic)
+struct PathLight { float x, y, z; };
 struct PersistArgs {
     uint32_t* cursor;           // [8][32] next path of each XCD group's share, one word per 128-byte line (zero before launch)
     const uint32_t* worklist;   // CACHE: pixels queued by the prepass
@@ -71,10 +74,10 @@ struct PersistArgs {
     const uint32_t* pinfo;
     const float4* sun_lut;      // [2*65536] per-frame shadow-ray table: direction, 1/|direction|
     const float4* dif_lut;      // [4*6*65536] diffuse-ray table, one 64-byte line per (face, noise byte pair): dir, normalized dir, 1/|dir|, per-frame sky(dir)
-    float4* pl;                 // [nsamples * nwork] light of each path (one 16-byte store per path)
+    PathLight* pl;              // [nsamples * nwork] light of each path (one 12-byte store per path)
     DevCounters* counters;
 };
-hipError_t launch_accumulate_paths(const Frame& f, const Planes& planes, const float4* pl, const uint32_t* worklist,
+hipError_t launch_accumulate_paths(const Frame& f, const Planes& planes, const PathLight* pl, const uint32_t* worklist,
                                    const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool last_batch,
                                    bool cache, float4* acc, hipStream_t st);
 hipError_t launch_sphere_lut(float4* lut, hipStream_t st);

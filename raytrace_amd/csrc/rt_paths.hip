@@ -286,7 +286,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
                 L = vadd(acc, light2);
             }
             const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
-            a.pl[Pitem] = make_float4(light.x, light.y, light.z, 0.0f);   // k_accumulate_paths adds a pixel's samples in order
+            a.pl[Pitem] = PathLight{light.x, light.y, light.z};   // k_accumulate_paths adds a pixel's samples in order
             Pst = PP_FINAL;
         }
         // ---- a diffuse ray hit: the next level stands on the hit point with the 0.001 face offset (:166-180)

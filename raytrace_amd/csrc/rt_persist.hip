@@ -15,7 +15,7 @@
 //                them — consume the results, shade, start the next level (directions come from tables), or finish
 //                the path and pull the next one from the wave's 128-path chunk of its XCD group's cursor (one atomicAdd per
 //                chunk, paths dealt out ballot-ranked) — so shading runs on a well-filled wave and the step loop on
-//                compacted work.  Per path one 16-byte light record goes to HBM; k_accumulate_paths adds a pixel's
+//                compacted work.  Per path one 12-byte light record goes to HBM; k_accumulate_paths adds a pixel's
 //                samples in order.
 //   k_persist2 : the same machinery regrouped — a lane carries two paths, each walking its level's shadow ray and then
 //                its diffuse ray in one ray slot (rt_dda.hpp); selectable (RT_KERNEL_PERSISTENT2), never the default.
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 }
             }
             if (path_done) {   // the path's light; k_accumulate_paths adds the samples of a pixel in order
-                a.pl[item] = make_float4(light.x, light.y, light.z, 0.0f);
+                a.pl[item] = PathLight{light.x, light.y, light.z};
                 phase = PH_EMPTY;
             }
         }
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
                 }
             }
             if (path_done) {   // the path's light; k_accumulate_paths adds the samples of a pixel in order
-                a.pl[C.item] = make_float4(light.x, light.y, light.z, 0.0f);
+                a.pl[C.item] = PathLight{light.x, light.y, light.z};
                 c2_set_phase(C, P2_EMPTY);
             }
         }
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes 
 // lighting planes itself (sum / spp / 16, raytrace.comp:352-356) — the prepass has done that for the pixels it finished —
 // so no separate resolve launch is needed.
 template <bool CACHE>
-__global__ __launch_bounds__(256) void k_accumulate_paths(Frame f, Planes planes, const float4* __restrict__ pl,
+__global__ __launch_bounds__(256) void k_accumulate_paths(Frame f, Planes planes, const PathLight* __restrict__ pl,
                                                           const uint32_t* __restrict__ worklist,
                                                           const uint32_t* __restrict__ wl_count, uint32_t npix_pad,
                                                           uint32_t nsamples, int first_batch, int last_batch, float4* __restrict__ acc) {
@@ -947,7 +947,7 @@ __global__ __launch_bounds__(256) void k_accumulate_paths(Frame f, Planes planes
     const uint32_t lp = CACHE ? worklist[w] : w;
     float4 v = first_batch ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : acc[lp];
     for (uint32_t b = 0; b < nsamples; b++) {
-        const float4 l = pl[(size_t)b * nwork + w];
+        const PathLight l = pl[(size_t)b * nwork + w];
         v.x = v.x + l.x; v.y = v.y + l.y; v.z = v.z + l.z;
     }
     if (last_batch) {
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256) void k_accumulate_paths(Frame f, Planes planes
     }
 }
 
-hipError_t launch_accumulate_paths(const Frame& f, const Planes& planes, const float4* pl, const uint32_t* worklist,
+hipError_t launch_accumulate_paths(const Frame& f, const Planes& planes, const PathLight* pl, const uint32_t* worklist,
                                    const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool last_batch,
                                    bool cache, float4* acc, hipStream_t st) {
     if (npix_pad == 0) return hipSuccess;

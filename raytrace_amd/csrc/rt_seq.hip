@@ -250,7 +250,7 @@ __global__ __launch_bounds__(1024) void k_seq(Scene sc, Frame f, Planes pl, Pers
                     L = vadd(acc, light2);
                 }
                 const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
-                a.pl[P.item] = make_float4(light.x, light.y, light.z, 0.0f);   // k_accumulate_paths adds a pixel's samples in order
+                a.pl[P.item] = PathLight{light.x, light.y, light.z};   // k_accumulate_paths adds a pixel's samples in order
                 P.st = PP_FINAL;
             } else {
                 // Diffuse result: material of the hit texel (:150-154), position with the 0.001 face offset (:166-180)
