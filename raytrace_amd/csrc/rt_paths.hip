@@ -419,7 +419,9 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             }
         }
         if (park == 0ull) break;   // nothing in flight, nothing parked, no paths left
+        __builtin_amdgcn_s_setprio(1);   // a wave in its pass holds 256 slot-lanes still: let it through (0.6 %)
         pass();
+        __builtin_amdgcn_s_setprio(0);
     }
     if (COUNT) {
         DevCounters* cn = a.counters;
