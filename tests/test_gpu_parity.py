@@ -484,6 +484,20 @@ def test_region_1024_matches_oracle(blue_noise, native_built):
                 assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn, region=1024)
         else:
             _compare(gpu, cpu, gcn, ccn)
+    # the same scene seen through a scrolled window (lr != 0): k_paths' scrolled-region build at region 1024, where the voxel
+    # index takes 30 bits next to the border flag
+    u = _uniforms(origin=(-104.0, -520.0, 410.0), seed=7, lr=(16, -32, 48))
+    W, H, spp, depth = 48, 32, 2, 3
+    cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth, region=1024)
+    cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=abi.RT_KERNEL_PATHS, flags=abi.RT_FLAG_CACHE_PRIMARY, region=1024)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(u)
+        ctx.sync()
+        assert ctx.kernel_in_use() == abi.RT_KERNEL_PATHS
+        gpu = ctx.readback_all()
+    _compare(gpu, cpu)
 
 
 @pytest.mark.parametrize("kernel", PATH_KERNELS)
