@@ -367,6 +367,38 @@ def test_full_size_properties(procedural_region, blue_noise, W, H, spp, depth):
         assert np.array_equal(a1[name][rows[0]:rows[1]], cpu[name][rows[0]:rows[1]], equal_nan=True), name
 
 
+def test_full_size_scrolled_region(blue_noise):
+    """The headline's frame size through a scrolled window (lr != 0 — every frame once the camera has travelled): RT_KERNEL_DEFAULT
+    runs k_paths' scrolled-region build there; the frame is deterministic, equals k_persist's (the generic wrap_texel walk) on
+    every plane, and a band of rows equals the oracle."""
+    lr = (48, 0, 32)
+    mats, mine = world.toroidal_region(lr)
+    u = _uniforms(origin=(18.0, -128.0, 132.0), seed=1, lr=lr)
+    W, H, spp, depth = 1920, 1080, 64, 4
+    frames = {}
+    for kernel in (abi.RT_KERNEL_DEFAULT, abi.RT_KERNEL_PERSISTENT):
+        cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=kernel, flags=abi.RT_FLAG_CACHE_PRIMARY)
+        with render.Context(cfg) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(u)
+            ctx.sync()
+            frames[kernel] = ctx.readback_all()
+            assert ctx.kernel_in_use() == (abi.RT_KERNEL_PATHS if kernel == abi.RT_KERNEL_DEFAULT else abi.RT_KERNEL_PERSISTENT)
+            if kernel == abi.RT_KERNEL_DEFAULT:
+                ctx.draw_frame(u)
+                ctx.sync()
+                again = ctx.readback_all()
+                for name in again:
+                    assert np.array_equal(again[name], frames[kernel][name], equal_nan=True), name
+    for name in frames[abi.RT_KERNEL_DEFAULT]:
+        assert np.array_equal(frames[abi.RT_KERNEL_DEFAULT][name], frames[abi.RT_KERNEL_PERSISTENT][name], equal_nan=True), name
+    rows = (500, 508)
+    cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth, rows=rows)
+    for name in cpu:
+        assert np.array_equal(frames[abi.RT_KERNEL_DEFAULT][name][rows[0]:rows[1]], cpu[name][rows[0]:rows[1]], equal_nan=True), name
+
+
 def test_bench_two_rank_rehearsal_assembles_the_same_frame():
     """bench.py's N>1 path on a one-GPU box: 2 ranks share GPU 0 and gather over gloo (RCCL needs one GPU per rank; the
     driver runs that).  The frame assembled on rank 0 must hash to the same value as the single-rank frame."""
