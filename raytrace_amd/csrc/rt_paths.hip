@@ -26,8 +26,7 @@
 // Built and measured without gain: passes specialised by what the parked level needs (6.08 against 5.3 ms); reserving the next
 // chunk of paths one pass ahead (4.83 against 4.64: the atomic's return sits in front of the pass's loads); the step group
 // software-pipelined by context, one context's arithmetic under the other's byte loads (4.98 against 4.65 — the loop wants its
-// four slots' accesses batched); the global-memory albedo stack of deep frames fetched as a column ahead of the sum (C4:
-// 137.7 against 123.9 ms, the registers it takes spill); nibble map and byte array biased by one so that "mixed or not" needs
+// four slots' accesses batched); nibble map and byte array biased by one so that "mixed or not" needs
 // no compare (2.5 % fewer loop instructions, 1 % slower: ended slots then keep fetching their byte); positions scaled by four
 // to share the table-index multiply (6 % fewer instructions, 1.7 % slower: more packed-math issue slots).
 //
@@ -58,18 +57,21 @@
 namespace rtd {
 using namespace pslot;
 
-// STK: where the albedo stack of the two paths lives — 0 = LDS (depth <= 4: three levels per path: the 24 KiB the nibble map
-// and the tables leave hold exactly 2 x 3 rows), 1 = global memory.  (Deeper frames with the first three levels in LDS and the
-// rest in global memory were measured on the 4K spp-256 depth-8 frame: 8.63 instead of 8.51 ms per launch.)
+// STK: where the albedo stack of the two paths lives — 0 = LDS (depth <= 4: three levels per path: the 24 KiB the nibble map and
+// the tables leave hold exactly 2 x 3 rows); 1 = global memory; 2 (depth 5..8 at region 256) = levels 1-3 in those LDS rows, levels
+// 4-7 in global memory and fetched with the pass's first batch of loads, so that the sum over a path's levels makes no round
+// trips of its own (the 4K spp-256 depth-8 frame: 6.75 ms per launch against 7.19 with the whole stack in global memory; LDS rows
+// alone: 7.14; the whole seven-level column fetched ahead: 8.40 — its registers spill).
 template <bool COUNT, int STK, int LOGR, bool LRZ>
 __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, PersistArgs a) {
     static_assert(LOGR == 8 || STK == 1, "the larger regions' tables leave no LDS for the albedo stack");
+    constexpr bool LDS_ROWS = STK == 0 || STK == 2;   // STK 2 (depth 5..8 at region 256): levels 1-3 in LDS, the rest in global memory
     constexpr int R = 1 << LOGR, LB = LOGR - 2;
     constexpr uint32_t kTabWords = swz_bytes<LOGR>() / 4u;   // 2 R entries per axis
     __shared__ uint32_t s_coarse[kCoarseWords];
     __shared__ __attribute__((aligned(swz_bytes<LOGR>()))) uint32_t s_swz[3 * kTabWords];   // swizzle tables (see p_advance)
     __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
-    __shared__ uint32_t s_stack[STK == 0 ? 2 : 1][STK == 0 ? 3 : 1][STK == 0 ? 1024 : 1];
+    __shared__ uint32_t s_stack[LDS_ROWS ? 2 : 1][LDS_ROWS ? 3 : 1][LDS_ROWS ? 1024 : 1];
     const uint32_t nwork = *a.wl_count;
     const uint32_t nitems = nwork * a.nsamples;
     if (nitems == 0u) return;
@@ -164,11 +166,17 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
 
     // albedo stack of context c: packed material of surface j+2 at slot j
     auto stack_at = [&](uint32_t c, uint32_t j) -> uint32_t {
-        if constexpr (STK == 0) return s_stack[c][j][threadIdx.x];
-        else return a.stack[((size_t)c * stack_levels + j) * a.nthreads + gtid];
+        if constexpr (STK == 0) {
+            return s_stack[c][j][threadIdx.x];
+        } else if constexpr (STK == 2) {
+            if (j < 3u) return s_stack[c][j][threadIdx.x];
+            return a.stack[((size_t)c * stack_levels + j) * a.nthreads + gtid];
+        } else {
+            return a.stack[((size_t)c * stack_levels + j) * a.nthreads + gtid];
+        }
     };
     auto stack_put = [&](uint32_t c, uint32_t j, uint32_t m) {
-        if constexpr (STK == 0) s_stack[c][j][threadIdx.x] = m;
+        if (LDS_ROWS && (STK == 0 || j < 3u)) s_stack[c][j][threadIdx.x] = m;
         else a.stack[((size_t)c * stack_levels + j) * a.nthreads + gtid] = m;
     };
 
@@ -269,6 +277,14 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         const uint32_t wgx8 = info & 0x3FFFu, wgy8 = (info >> 14) & 0x3FFFu;
         const uint32_t ntx = ((nb & 0xFFu) + wgx8) & 511u, nty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
         const uint32_t nse = sc.noise[nty * RT_NOISE_SIZE + ntx] & 0xFFFFu;   // second round trip, new paths only
+        // depth 5..8 at region 256: the stack levels that live in global memory (4..7) ride in the first batch — the sum below
+        // then makes no round trips of its own
+        uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
+        if constexpr (STK == 2) {
+            const size_t col = (size_t)c * stack_levels * a.nthreads + gtid;
+            pf0 = a.stack[col + (size_t)min(3u, stack_levels - 1u) * a.nthreads]; pf1 = a.stack[col + (size_t)min(4u, stack_levels - 1u) * a.nthreads];
+            pf2 = a.stack[col + (size_t)min(5u, stack_levels - 1u) * a.nthreads]; pf3 = a.stack[col + (size_t)min(6u, stack_levels - 1u) * a.nthreads];
+        }
 
         // ---- a path ends: L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
         uint32_t sunbits = Pst & 0xFFFFu;
@@ -278,7 +294,13 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             if (sunbits >> (level - 1u) & 1u) L = vadd(L, sunlight);
             if (air) L = vadd(L, v3(skyv.x, skyv.y, skyv.z));
             for (uint32_t j = level - 1u; j >= 1u; j--) {
-                const uint32_t pm = stack_at(c, j - 1u);
+                uint32_t pm;
+                if constexpr (STK == 2) {
+                    const uint32_t k = j - 1u;
+                    pm = k < 3u ? s_stack[c][k < 3u ? k : 0u][threadIdx.x] : (k == 3u ? pf0 : (k == 4u ? pf1 : (k == 5u ? pf2 : pf3)));
+                } else {
+                    pm = stack_at(c, j - 1u);
+                }
                 vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
                 light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
                 vec3 acc = v3(0.0f, 0.0f, 0.0f);
@@ -441,14 +463,14 @@ hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const
                         hipStream_t st) {
     if (f.logr < 8 || f.logr > 10) return hipErrorInvalidValue;
     const dim3 grid(nworkgroups), block(1024);
-    // albedo stack: LDS for depth <= 4 at region 256 (the larger regions' swizzle tables take the LDS it would need), else global
+    // albedo stack: see STK (the larger regions' swizzle tables take the LDS rows)
     const bool lds_stack = f.depth <= 4 && f.logr == 8;
     const bool lrz = f.lr_zero != 0;   // false: a scrolled region (rt_pslot.hpp, p_advance)
 #define RT_LAUNCH_PATHS(C, S, L, Z) hipLaunchKernelGGL((k_paths<C, S, L, Z>), grid, block, 0, st, sc, f, pl, a)
 #define RT_LAUNCH_PATHS_CZ(S, L) do { if (count) { if (lrz) RT_LAUNCH_PATHS(true, S, L, true); else RT_LAUNCH_PATHS(true, S, L, false); } \
                                       else { if (lrz) RT_LAUNCH_PATHS(false, S, L, true); else RT_LAUNCH_PATHS(false, S, L, false); } } while (0)
     if (f.logr == 8) {
-        if (lds_stack) RT_LAUNCH_PATHS_CZ(0, 8); else RT_LAUNCH_PATHS_CZ(1, 8);
+        if (lds_stack) RT_LAUNCH_PATHS_CZ(0, 8); else if (f.depth <= 8) RT_LAUNCH_PATHS_CZ(2, 8); else RT_LAUNCH_PATHS_CZ(1, 8);
     } else if (f.logr == 9) {
         RT_LAUNCH_PATHS_CZ(1, 9);
     } else {
