@@ -660,8 +660,8 @@ def test_headline_frame_equals_the_oracle(procedural_region, blue_noise):
     assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
 
 
-# ---- BASELINE.json config C4: 3840x2160, spp 256, depth 8 (sixteen k_persist-sized batches on the old kernel, one launch on
-# ---- k_paths), as one context and as the eight-way tile split the 8-GPU run uses -------------------------------------------
+# ---- BASELINE.json config C4: 3840x2160, spp 256, depth 8 (three launches of up to 86 samples on one GPU, one per tile-split
+# ---- context), as one context and as the eight-way tile split the 8-GPU run uses -------------------------------------------
 C4 = (3840, 2160, 256, 8)
 
 
