@@ -100,6 +100,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     // minefield bytes as a buffer: a lane that needs no byte passes an out-of-range offset (no access, returns 0)
     const auto mine_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sc.mine), (short)0, 1 << (3 * LOGR), 0x00020000);
 
+#ifdef RT_DIAG_WAVE_TIMES
+    const unsigned long long t_wave0 = wall_clock64();
+    unsigned long long t_exh = 0;
+#endif
     PSlot SA, FA, SB, FB;
     SA.px = SA.py = SA.pz = SA.ndx = SA.ndy = SA.lx = SA.ly = SA.lz = 0.0f; SA.ndz = -1.0f;
     SA.sx = SA.sy = SA.sz = 0u; SA.nk = K_DEAD | K_END; SA.axis = 2u;
@@ -399,7 +403,9 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             uint64_t idleA = 0ull, idleB = 0ull;   // lanes whose context is empty for good (no paths left)
             if (exhausted) { idleA = __ballot((PA.st >> 20) == 0u); idleB = __ballot((PB.st >> 20) == 0u); }
             park = (eA & ~idleA) | (eB & ~idleB);
-            if ((uint32_t)__popcll(park) >= threshold || (eA & eB) == ~0ull) break;
+            // (once the paths have run out nobody refills the wave: two parked lanes are then enough — 0.7 %; a wave spends the last
+            // 4 % of its life in that state and the kernel's last 4 % waiting for its slowest waves: RT_DIAG_WAVE_TIMES)
+            if ((uint32_t)__popcll(park) >= (exhausted ? 2u : threshold) || (eA & eB) == ~0ull) break;
             if (COUNT) { d_iters++; d_live += (uint32_t)__popcll(~eA) + (uint32_t)__popcll(~eB); }
             // ---- one step of all four slots: nibble reads, then byte loads, then the arithmetic ----
 #pragma unroll
@@ -441,6 +447,9 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             }
         }
         if (park == 0ull) break;   // nothing in flight, nothing parked, no paths left
+#ifdef RT_DIAG_WAVE_TIMES
+        if (exhausted && !t_exh) t_exh = wall_clock64();
+#endif
         __builtin_amdgcn_s_setprio(1);   // a wave in its pass holds 256 slot-lanes still: let it through (0.6 %)
         pass();
         __builtin_amdgcn_s_setprio(0);
@@ -455,6 +464,11 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         if (lane == 0) {
             atomicAdd(&cn->dbg_loop_iters, d_iters); atomicAdd(&cn->dbg_f_lanes, d_live);
             atomicAdd(&cn->dbg_passes, d_passf); atomicAdd(&cn->dbg_pass_lanes, d_plf);
+#ifdef RT_DIAG_WAVE_TIMES
+            const unsigned long long t1 = wall_clock64();
+            atomicAdd(&cn->dbg_s_execs, t1 - t_wave0); atomicMax(&cn->dbg_f_execs, t1); atomicMax(&cn->dbg_sky_lanes, ~t_wave0);
+            atomicAdd(&cn->dbg_s_lanes, t_exh ? t1 - t_exh : 0ull);
+#endif
         }
     }
 }
