@@ -1,7 +1,8 @@
-// rt_paths.hip — k_paths, the path kernel RT_KERNEL_DEFAULT runs for cached-primary frames with lr = 0.
+// rt_paths.hip — k_paths, the path kernel RT_KERNEL_DEFAULT runs for cached-primary frames (launches of 6 M paths and more).
 //
 // Same work, same values as k_persist (rt_persist.hip); what differs is how much of it a wave keeps in flight and how the
-// instructions are spent (measured on gfx950, DESIGN.md 5: the step loop is bound by VALU issue — tools/ubench/valu_rate.hip — the transition passes by memory latency):
+// instructions are spent (measured on gfx950, DESIGN.md 5: the step loop is bound by VALU issue — tools/ubench/valu_rate.hip —
+// the transition passes by memory latency):
 //   * a lane carries TWO paths (contexts A and B), each with the level's shadow ray and diffuse ray in their own ray slots:
 //     four independent fetch chains per lane instead of two.  k_persist ran at an LDS-pinned four waves per SIMD with 75 of
 //     its 128 VGPRs and its waves parked at s_waitcnt half of their life (round-1 counters); the idle registers now hold
