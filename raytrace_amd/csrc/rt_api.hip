@@ -398,15 +398,15 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         RT_HIP_CREATE(dev_alloc(c, &c->sun_lut, (size_t)2 * 65536));
         RT_HIP_CREATE(dev_alloc(c, &c->dif_lut, (size_t)4 * 6 * 65536));
         RT_HIP_CREATE(dev_alloc(c, &c->pacc, (size_t)c->npix_pad));
-        {   // samples per path-kernel launch: bounded by 2^30 work items and by the memory given to the per-path light records —
-            // 16 GiB of the 288 (RT_PERSIST_LIGHT_GIB): every launch pays its ramp-up and its tail, so fewer and longer ones win
+        {   // samples per path-kernel launch: bounded by 2^31 work items and by the memory given to the per-path light records —
+            // 16 GiB of the 288 (RT_PERSIST_LIGHT_GIB; 32 GiB: another 0.3-0.5 %): every launch pays its ramp-up and its tail, so fewer and longer ones win
             // (3840x2160 spp 256 depth 8: 114.1 ms per frame with 1 GiB, 109.3 with 2, 107.0 with 4, 105.6 with 8 and beyond;
             // the 1024^3 spp-1024 frame: 158.1 with 2 GiB, 138.7 with 8, 136.1 with 32); halved until the allocation succeeds
             uint64_t np = c->npix_pad ? c->npix_pad : 1;
             uint64_t light_bytes = 16ull << 30;
             if (const char* s = getenv("RT_PERSIST_LIGHT_GIB")) { long long v = atoll(s); if (v >= 1 && v <= 128) light_bytes = (uint64_t)v << 30; }
             uint64_t B = light_bytes / (sizeof(rtd::PathLight) * np);
-            if (B > (1ull << 30) / np) B = (1ull << 30) / np;
+            if (B > (1ull << 31) / np) B = (1ull << 31) / np;   // path indices are 32-bit
             if (const char* s = getenv("RT_PERSIST_BATCH")) { long long v = atoll(s); if (v > 0 && (uint64_t)v < B) B = (uint64_t)v; }   // may only lower the bound
             if (B < 1) B = 1;
             if (B > (uint64_t)cfg->spp) B = (uint64_t)cfg->spp;
