@@ -208,9 +208,21 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
  * offset (command_buffer.rs:262-298): replace one 16-thick slab of the region.  axis 0/1/2 = x/y/z;
  * texel_offset (multiple of 16, < 256) is the slab's start along that axis; the data is a dense box of
  * extent (16,R,R) / (R,16,R) / (R,R,16), x fastest (terrain_upload.rs:96-100).  Only the slab is re-tiled on the device (one
- * launch over its 16 R^2 voxels + the nibble-map words it touches); any region size. */
+ * launch over its 16 R^2 voxels + the nibble-map words it touches); any region size.
+ * Asynchronous: the slab is copied into pinned staging (the host's buffers are free again at return), transferred on the
+ * library's upload stream and applied on the context's stream after the frames already submitted — the call does not wait
+ * for them (the reference does: vkQueueWaitIdle, pipeline.rs:181-189).  Without RT_FLAG_TRUSTED_WORLD the staged minefield
+ * is checked first (values above 30 -> RT_ERR_INVALID_ARG); a rejected slab is NOT applied: the region and what can be
+ * drawn stay as they were. */
 int rt_upload_slice(RtContext* ctx, int axis, int texel_offset,
                     const uint32_t* materials, const uint8_t* minefield);
+
+/* The upload buffers of TerrainUploadManager::new (terrain_upload.rs:65-82) are host-visible mapped Vulkan buffers the CPU
+ * fills in place; this is their counterpart: pinned host memory for ONE slab (u32[16 R^2] materials, u8[16 R^2] minefield).
+ * A host that assembles its slab there and hands these very pointers to rt_upload_slice saves the copy into the staging
+ * buffer.  The memory is the host's to write from the return of this call until its next rt_upload_slice (the call waits
+ * until the previous slab's transfer has left the buffer); it lives as long as the context. */
+int rt_slice_staging(RtContext* ctx, uint32_t** materials, uint8_t** minefield);
 
 /* Blue-noise table (render_data.rs:110-133; decoded by structures.rs:496-517): RGBA8 512x512. */
 int rt_upload_noise(RtContext* ctx, const uint8_t* rgba8);

@@ -12,7 +12,7 @@ LIB_HOST_PATH = os.path.join(HERE, "librt_host.so")
 
 # Every symbol include/rt_abi.h declares.
 ABI_SYMBOLS = (
-    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_world", "rt_upload_slice", "rt_upload_noise",
+    "rt_create", "rt_destroy", "rt_last_error", "rt_upload_world", "rt_upload_slice", "rt_slice_staging", "rt_upload_noise",
     "rt_draw_frame", "rt_sync", "rt_readback", "rt_buffer_bytes", "rt_device_ptr", "rt_set_stream",
     "rt_tile_count", "rt_tile_capacity", "rt_untile", "rt_gbuffer_ptr", "rt_gbuffer_bytes", "rt_gbuffer_offset",
     "rt_untile_gbuffer", "rt_denoise", "rt_finalize", "rt_denoise_planes", "rt_finalize_planes", "rt_kernel_in_use", "rt_get_counters", "rt_reset_counters", "rt_get_timing",
@@ -47,6 +47,7 @@ def amd():
         lib.rt_last_error.restype = C.c_char_p
         lib.rt_upload_world.argtypes = [P, P, P]
         lib.rt_upload_slice.argtypes = [P, C.c_int, C.c_int, P, P]
+        lib.rt_slice_staging.argtypes = [P, C.POINTER(P), C.POINTER(P)]
         lib.rt_upload_noise.argtypes = [P, P]
         lib.rt_draw_frame.argtypes = [P, C.POINTER(RtUniforms)]
         lib.rt_sync.argtypes = [P]
@@ -90,7 +91,7 @@ def amd():
         lib.rt_selftest.restype = C.c_int
         for name in ("rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_gather_gbuffer"):
             getattr(lib, name).restype = C.c_int
-        for name in ("rt_upload_world", "rt_upload_slice", "rt_upload_noise", "rt_draw_frame", "rt_sync", "rt_readback",
+        for name in ("rt_upload_world", "rt_upload_slice", "rt_slice_staging", "rt_upload_noise", "rt_draw_frame", "rt_sync", "rt_readback",
                      "rt_set_stream", "rt_tile_count", "rt_tile_capacity", "rt_untile", "rt_untile_gbuffer", "rt_denoise", "rt_finalize",
                      "rt_denoise_planes", "rt_finalize_planes", "rt_get_counters",
                      "rt_reset_counters", "rt_get_timing"):
@@ -157,6 +158,7 @@ def host():
         lib.rth_game_get_sun_angle.argtypes = [P]
         lib.rth_game_get_sun_angle.restype = C.c_float
         lib.rth_game_set_world.argtypes = [P, P, P]
+        lib.rth_game_set_world_r.argtypes = [P, P, P, C.c_int]
         lib.rth_game_generate_world.argtypes = [P, C.c_uint64]
         lib.rth_game_generate_world_r.argtypes = [P, C.c_uint64, C.c_int]
         lib.rth_create_instance.argtypes = [C.POINTER(RtConfig), P, P, P, C.c_size_t]

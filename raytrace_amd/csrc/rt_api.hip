@@ -41,13 +41,17 @@ struct RtContext {
     std::string err = "";
     bool has_world = false, has_noise = false;
     bool world_resident = false;          // a full region has been uploaded once (slabs may patch it)
-    int bad_slab_axis = -1, bad_slab_offset = -1;   // a rejected slab sits in the region: not drawable until that slab is replaced
 
     // scene
     uint8_t* d_mine_lin = nullptr; uint32_t* d_mat_lin = nullptr;
     uint8_t* d_mine_sw = nullptr; uint32_t* d_mat_sw = nullptr;
     uint32_t* d_coarse = nullptr; uint32_t* d_noise = nullptr; uint32_t* d_flag = nullptr;
-    uint8_t* d_slab_mine = nullptr; uint32_t* d_slab_mat = nullptr;   // rt_upload_slice staging: one 16-thick slab
+    // rt_upload_slice: one 16-thick slab travels pinned host staging -> device staging (own stream) -> re-tile (render stream)
+    uint8_t* d_slab_mine = nullptr; uint32_t* d_slab_mat = nullptr; uint32_t* d_slab_flag = nullptr;
+    uint8_t* h_slab_mine = nullptr; uint32_t* h_slab_mat = nullptr; uint32_t* h_slab_flag = nullptr;   // hipHostMalloc
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t ev_slab_copied = nullptr, ev_slab_applied = nullptr;   // host staging read / device staging consumed
+    bool slab_copy_pending = false, slab_apply_recorded = false;
 
     // tiling
     int tiles_x = 0, tiles_y = 0, ntiles_total = 0, ntiles_local = 0, tile_capacity = 0;
@@ -96,6 +100,7 @@ struct RtContext {
     bool lut_valid = false;
     int primary_version = 2;      // 1 = k_primary (thread per pixel), 2 = k_primary2 (nibble map in LDS); RT_PRIMARY_V
     rtd::DevCounters* d_counters = nullptr;
+    unsigned long long* d_selftest = nullptr;
     uint64_t host_noise_base = 0, host_frames = 0;
 
     // timing
@@ -457,6 +462,12 @@ void rt_destroy(RtContext* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->stream && ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
+    if (ctx->ev_slab_copied) (void)hipEventDestroy(ctx->ev_slab_copied);
+    if (ctx->ev_slab_applied) (void)hipEventDestroy(ctx->ev_slab_applied);
+    if (ctx->h_slab_mat) (void)hipHostFree(ctx->h_slab_mat);
+    if (ctx->h_slab_mine) (void)hipHostFree(ctx->h_slab_mine);
+    if (ctx->h_slab_flag) (void)hipHostFree(ctx->h_slab_flag);
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ev_frame0) (void)hipEventDestroy(ctx->ev_frame0);
@@ -490,7 +501,35 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
     if (rc != RT_OK) return rc;
     ctx->has_world = true;
     ctx->world_resident = true;
-    ctx->bad_slab_axis = ctx->bad_slab_offset = -1;
+    return RT_OK;
+}
+
+namespace {
+// staging of rt_upload_slice, created on first use: pinned host memory for one slab (the reference's upload buffers are
+// host-visible mapped Vulkan buffers, terrain_upload.rs:65-82), its device twin, a stream for the transfer and two events
+int slab_resources(RtContext* ctx) {
+    const size_t n = (size_t)RT_SLICE_SIZE * (size_t)ctx->region * (size_t)ctx->region;
+    if (!ctx->d_slab_mat) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mat, n));
+    if (!ctx->d_slab_mine) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mine, n));
+    if (!ctx->d_slab_flag) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_flag, 1));
+    if (!ctx->h_slab_mat) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_mat, n * sizeof(uint32_t), hipHostMallocDefault));
+    if (!ctx->h_slab_mine) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_mine, n, hipHostMallocDefault));
+    if (!ctx->h_slab_flag) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_flag, sizeof(uint32_t), hipHostMallocDefault));
+    if (!ctx->upload_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    if (!ctx->ev_slab_copied) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_copied, hipEventDisableTiming));
+    if (!ctx->ev_slab_applied) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_applied, hipEventDisableTiming));
+    return RT_OK;
+}
+}  // namespace
+
+int rt_slice_staging(RtContext* ctx, uint32_t** materials, uint8_t** minefield) {
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!materials || !minefield) return fail(ctx, RT_ERR_INVALID_ARG, "rt_slice_staging: null pointer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = slab_resources(ctx);
+    if (rc != RT_OK) return rc;
+    if (ctx->slab_copy_pending) { RT_HIP(ctx, hipEventSynchronize(ctx->ev_slab_copied)); ctx->slab_copy_pending = false; }   // the previous slab has left it
+    *materials = ctx->h_slab_mat; *minefield = ctx->h_slab_mine;
     return RT_OK;
 }
 
@@ -502,35 +541,45 @@ int rt_upload_slice(RtContext* ctx, int axis, int texel_offset, const uint32_t* 
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_slice: bad axis or offset");
     if (!ctx->world_resident) return fail(ctx, RT_ERR_NOT_READY, "rt_upload_slice: upload the full region first");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));          // frames in flight still read the region
-    // Incremental: the slab goes to a staging buffer (5 bytes x 16 x R^2), ONE launch re-tiles just its 16 R^2 voxels into the
-    // brick-swizzled arrays and a second rebuilds the nibble-map words it touches (<= 4 x 64^2 entries) — not the whole
-    // region (the full re-flatten moved 80 MiB for a 5 MiB slab).
+    int rc = slab_resources(ctx);
+    if (rc != RT_OK) return rc;
+    // Incremental and asynchronous.  The slab goes pinned host staging -> device staging (5 bytes x 16 x R^2) on the upload
+    // stream; the render stream waits for that event (not the host), then ONE launch re-tiles the slab's 16 R^2 voxels into the
+    // brick-swizzled arrays and a second rebuilds the nibble-map words it touches.  Frames in flight keep reading the region
+    // until then by stream order — no hipStreamSynchronize on the render stream (the reference blocks on vkQueueWaitIdle here,
+    // pipeline.rs:181-189).
     const size_t n = (size_t)RT_SLICE_SIZE * kR * kR;
-    if (!ctx->d_slab_mat) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mat, n));
-    if (!ctx->d_slab_mine) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mine, n));
-    // from here on the resident copy is being modified: a failure leaves no drawable world (as in rt_upload_world)
-    ctx->has_world = false;
-    RT_HIP(ctx, hipMemcpy(ctx->d_slab_mat, materials, n * sizeof(uint32_t), hipMemcpyHostToDevice));   // blocking: the host
-    RT_HIP(ctx, hipMemcpy(ctx->d_slab_mine, minefield, n, hipMemcpyHostToDevice));                      // buffers are borrowed
+    if (ctx->slab_copy_pending) { RT_HIP(ctx, hipEventSynchronize(ctx->ev_slab_copied)); ctx->slab_copy_pending = false; }
+    if (materials != ctx->h_slab_mat) memcpy(ctx->h_slab_mat, materials, n * sizeof(uint32_t));   // borrowed buffers are released at return;
+    if (minefield != ctx->h_slab_mine) memcpy(ctx->h_slab_mine, minefield, n);                     // rt_slice_staging's pointers need no copy
+    if (ctx->slab_apply_recorded) RT_HIP(ctx, hipStreamWaitEvent(ctx->upload_stream, ctx->ev_slab_applied, 0));   // the previous slab's re-tile has read the device staging
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_slab_mine, ctx->h_slab_mine, n, hipMemcpyHostToDevice, ctx->upload_stream));
     const bool validate = (ctx->cfg.flags & RT_FLAG_TRUSTED_WORLD) == 0;
-    if (validate) RT_HIP(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(uint32_t), ctx->stream));
+    if (validate) {
+        // values above 30 are rejected as in rt_upload_world — BEFORE anything is written: a rejected slab leaves the region
+        // (and what can be drawn) as it was.  The check reads the staged bytes on the upload stream, so its round trip does
+        // not wait for frames in flight; a host that vouches for its data (RT_FLAG_TRUSTED_WORLD) skips it.
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_slab_flag, 0, sizeof(uint32_t), ctx->upload_stream));
+        RT_HIP(ctx, rtd::launch_check_slab(ctx->d_slab_mine, n, ctx->d_slab_flag, ctx->upload_stream));
+        RT_HIP(ctx, hipMemcpyAsync(ctx->h_slab_flag, ctx->d_slab_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->upload_stream));
+    }
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_slab_mat, ctx->h_slab_mat, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->upload_stream));
+    RT_HIP(ctx, hipEventRecord(ctx->ev_slab_copied, ctx->upload_stream));
+    ctx->slab_copy_pending = true;
+    if (validate) {
+        RT_HIP(ctx, hipEventSynchronize(ctx->ev_slab_copied));
+        ctx->slab_copy_pending = false;
+        if (*ctx->h_slab_flag)
+            return fail(ctx, RT_ERR_INVALID_ARG, "minefield slab holds a value above 30 (the reference writes 0..6, src/world/chunk.rs:163-183); the region is unchanged");
+    }
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slab_copied, 0));
     {
         LaunchTimer t(ctx, 1);
-        RT_HIP(ctx, rtd::launch_flatten_slab(ctx->d_slab_mine, ctx->d_slab_mat, ctx->d_mine_sw, ctx->d_mat_sw, ctx->d_coarse, ctx->d_flag,
+        RT_HIP(ctx, rtd::launch_flatten_slab(ctx->d_slab_mine, ctx->d_slab_mat, ctx->d_mine_sw, ctx->d_mat_sw, ctx->d_coarse,
                                              ctx->logr, axis, texel_offset, ctx->stream));
     }
-    if (validate) {   // values above 30 are rejected like in rt_upload_world; a host that vouches for its data skips the round trip
-        uint32_t flag = 0;
-        RT_HIP(ctx, hipMemcpyAsync(&flag, ctx->d_flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (flag) {   // the slab is in the region already: nothing is drawn until this very slab is replaced (or the region re-uploaded)
-            ctx->bad_slab_axis = axis; ctx->bad_slab_offset = texel_offset;
-            return fail(ctx, RT_ERR_INVALID_ARG, "minefield slab holds a value above 30 (the reference writes 0..6, src/world/chunk.rs:163-183)");
-        }
-    }
-    if (ctx->bad_slab_axis == axis && ctx->bad_slab_offset == texel_offset) ctx->bad_slab_axis = ctx->bad_slab_offset = -1;
-    ctx->has_world = ctx->bad_slab_axis < 0;
+    RT_HIP(ctx, hipEventRecord(ctx->ev_slab_applied, ctx->stream));
+    ctx->slab_apply_recorded = true;
     return RT_OK;
 }
 
@@ -868,10 +917,19 @@ int rt_gather_gbuffer(RtContext* ctx, void* comm_, int root, void* const* frames
     // every rank sends its block to the root; the root posts one receive per rank (its own block included).  Each peer uses
     // its own xGMI link into the root, so the transfers run in parallel.
     RT_NCCL(ctx, g_rccl.GroupStart());
-    if (rank == root)
-        for (int r = 0; r < world; r++) RT_NCCL(ctx, g_rccl.Recv(ctx->gathered[s] + (size_t)r * gb, gb, ncclUint8, r, comm, gs));
-    RT_NCCL(ctx, g_rccl.Send(src, gb, ncclUint8, root, comm, gs));
-    RT_NCCL(ctx, g_rccl.GroupEnd());
+    {   // a failing call must not leave the group open: the group is always closed, the first error is reported
+        ncclResult_t first = ncclSuccess;
+        const char* what = "";
+        if (rank == root)
+            for (int r = 0; r < world && first == ncclSuccess; r++) {
+                first = g_rccl.Recv(ctx->gathered[s] + (size_t)r * gb, gb, ncclUint8, r, comm, gs);
+                what = "ncclRecv";
+            }
+        if (first == ncclSuccess) { first = g_rccl.Send(src, gb, ncclUint8, root, comm, gs); what = "ncclSend"; }
+        const ncclResult_t end = g_rccl.GroupEnd();
+        if (first == ncclSuccess && end != ncclSuccess) { first = end; what = "ncclGroupEnd"; }
+        if (first != ncclSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_gather_gbuffer: ") + what + ": " + g_rccl.GetErrorString(first));
+    }
     if (rank == root) {
         const int capacity = (ctx->ntiles_total + world - 1) / world;
         for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++) {
@@ -894,8 +952,8 @@ int rt_selftest(RtContext* ctx, int which, uint64_t* result) {
     if (!ctx || !result) return RT_ERR_INVALID_ARG;
     if (which != RT_SELFTEST_DENOISE_DIVISION) return fail(ctx, RT_ERR_INVALID_ARG, "rt_selftest: unknown test");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned long long* d = nullptr;
-    RT_HIP(ctx, dev_alloc(ctx, &d, 1));
+    if (!ctx->d_selftest) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_selftest, 1));   // one word, allocated once
+    unsigned long long* d = ctx->d_selftest;
     RT_HIP(ctx, hipMemsetAsync(d, 0, sizeof(*d), ctx->stream));
     RT_HIP(ctx, rtd::launch_selftest_dn_div(d, ctx->stream));
     unsigned long long h = 0;

@@ -42,10 +42,10 @@ __global__ __launch_bounds__(256) void k_flatten_voxels(const uint8_t* __restric
 // rt_upload_slice: the same re-tiling for ONE 16-thick slab (TerrainUploadManager::upload_slice, terrain_upload.rs:84-275 ->
 // vkCmdCopyBufferToImage with an offset).  The slab arrives as a dense box of extent 16 along `axis` and R along the other
 // two (x fastest); thread i handles swizzled voxel i of the slab's bricks — 4 brick layers along `axis`, whole bricks, so every
-// thread writes inside one 64-byte line run.  Values above kMaxStepValue raise the flag as in the full upload.
+// thread writes inside one 64-byte line run.  (The slab's values were checked before it got here: k_check_slab.)
 __global__ __launch_bounds__(256) void k_flatten_slab(const uint8_t* __restrict__ mine_slab, const uint32_t* __restrict__ mat_slab,
                                                       uint8_t* __restrict__ mine_sw, uint32_t* __restrict__ mat_sw,
-                                                      uint32_t* __restrict__ bad_value_flag, int logr, int axis, int offset) {
+                                                      int logr, int axis, int offset) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // grid covers exactly 16 * R^2
     const int lb = logr - 2;
     const uint32_t bmask = (1u << lb) - 1u;
@@ -64,10 +64,21 @@ __global__ __launch_bounds__(256) void k_flatten_slab(const uint8_t* __restrict_
     const uint32_t ex = axis == 0 ? (uint32_t)RT_SLICE_SIZE : R, ey = axis == 1 ? (uint32_t)RT_SLICE_SIZE : R;
     const size_t src = ((size_t)sz * ey + sy) * ex + sx;
     const size_t dst = ((((size_t)bc[2] << lb) + bc[1]) << lb) + bc[0];
-    const uint8_t v = mine_slab[src];
-    if (v > kMaxStepValue) atomicOr(bad_value_flag, 1u);
-    mine_sw[(dst << 6) | l] = v;
+    mine_sw[(dst << 6) | l] = mine_slab[src];
     mat_sw[(dst << 6) | l] = mat_slab[src];
+}
+
+// rt_upload_slice, before anything is written: does the staged slab hold a minefield value above kMaxStepValue (the reference
+// writes 0..6, chunk.rs:163-183)?  16 bytes per thread; n is a multiple of 4096.
+__global__ __launch_bounds__(256) void k_check_slab(const uint4* __restrict__ mine_slab, uint32_t nvec, uint32_t* __restrict__ bad_value_flag) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nvec) return;
+    const uint4 v = mine_slab[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    bool bad = false;
+    for (int k = 0; k < 4; k++)
+        for (int b = 0; b < 4; b++) bad = bad || ((w[k] >> (8 * b)) & 0xFFu) > kMaxStepValue;
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(bad_value_flag, 1u);
 }
 
 // One thread per nibble-map word = 8 consecutive coarse cubes (x-adjacent).  A coarse cube has edge R/64 and is made of
@@ -529,10 +540,16 @@ hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint
     return hipGetLastError();
 }
 
+hipError_t launch_check_slab(const uint8_t* mine_slab, size_t nbytes, uint32_t* bad_flag, hipStream_t st) {
+    const uint32_t nvec = (uint32_t)(nbytes / 16u);
+    hipLaunchKernelGGL(k_check_slab, dim3((nvec + 255u) / 256u), dim3(256), 0, st, reinterpret_cast<const uint4*>(mine_slab), nvec, bad_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_flatten_slab(const uint8_t* mine_slab, const uint32_t* mat_slab, uint8_t* mine_sw, uint32_t* mat_sw, uint32_t* coarse,
-                               uint32_t* bad_flag, int logr, int axis, int offset, hipStream_t st) {
+                               int logr, int axis, int offset, hipStream_t st) {
     const uint32_t R = 1u << logr;
-    hipLaunchKernelGGL(k_flatten_slab, dim3(RT_SLICE_SIZE * R * R / 256u), dim3(256), 0, st, mine_slab, mat_slab, mine_sw, mat_sw, bad_flag,
+    hipLaunchKernelGGL(k_flatten_slab, dim3(RT_SLICE_SIZE * R * R / 256u), dim3(256), 0, st, mine_slab, mat_slab, mine_sw, mat_sw,
                        logr, axis, offset);
     // nibble-map entries the slab touches: coarse cubes have edge R/64, so 16 voxels are 1024/R layers (4, 2, 1) — rounded out
     // to whole words along x (a word holds 8 x-adjacent cubes, all recomputed from the re-tiled bytes)

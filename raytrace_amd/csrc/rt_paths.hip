@@ -313,7 +313,11 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
                 L = vadd(acc, light2);
             }
             const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
+#ifndef RT_DIAG_NO_PL_STORE   // diagnostic build (tools/variant.sh nopl rt_paths.hip -DRT_DIAG_NO_PL_STORE): wrong frames, timing only
             a.pl[Pitem] = PathLight{light.x, light.y, light.z};   // k_accumulate_paths adds a pixel's samples in order
+#else
+            if (light.x == 12345.678f) a.pl[Pitem] = PathLight{light.x, light.y, light.z};   // keeps the unwinding alive, never stores
+#endif
             Pst = PP_FINAL;
         }
         // ---- a diffuse ray hit: the next level stands on the hit point with the 0.001 face offset (:166-180)

@@ -197,6 +197,9 @@ float rth_game_get_sun_angle(void* g) { return static_cast<game::Game*>(g)->get_
 int rth_game_set_world(void* g, const uint32_t* materials, const uint8_t* minefield) {
     return static_cast<game::Game*>(g)->set_world(materials, minefield);
 }
+int rth_game_set_world_r(void* g, const uint32_t* materials, const uint8_t* minefield, int region) {
+    return static_cast<game::Game*>(g)->set_world(materials, minefield, region);
+}
 int rth_game_generate_world(void* g, uint64_t seed) { return static_cast<game::Game*>(g)->generate_world(seed); }
 int rth_game_generate_world_r(void* g, uint64_t seed, int region) { return static_cast<game::Game*>(g)->generate_world(seed, region); }
 

@@ -32,7 +32,12 @@ Pipeline* create_instance(const RtConfig& cfg, const uint8_t* blue_noise_rgba8, 
         return nullptr;
     };
     if (!blue_noise_rgba8) { if (error) *error = "blue noise table is required"; return nullptr; }
-    if (!game.has_world() || game.world_region() != cfg.region) game.generate_world(0x5EED, cfg.region);
+    if (!game.has_world()) game.generate_world(0x5EED, cfg.region);
+    if (game.world_region() != cfg.region) {   // a world the caller set is never replaced behind their back
+        if (error) *error = "create_instance: the game's world has region " + std::to_string(game.world_region()) + " but the config asks for " +
+                            std::to_string(cfg.region);
+        return nullptr;
+    }
     RtContext* ctx = nullptr;
     if (rt_create(&cfg, &ctx) != RT_OK) return fail("rt_create", nullptr);
     if (rt_upload_world(ctx, game.world_materials(), game.world_minefield()) != RT_OK) return fail("rt_upload_world", ctx);
@@ -77,6 +82,12 @@ int Pipeline::draw_frame(game::Game& game) {
     if (tum_) {                                                      // pipeline.rs:174-189
         const long towards[3] = {(long)camera.origin[0], 0, (long)camera.origin[2]};   // (x, literal 0, z) — :175-179
         tum_->request_move_towards(towards);
+        if (tum_->pending() > 0) {   // the slab is assembled in the library's pinned staging (the reference's mapped upload buffers, terrain_upload.rs:65-82)
+            uint32_t* sm = nullptr; uint8_t* sf = nullptr;
+            rc = rt_slice_staging(ctx_, &sm, &sf);
+            if (rc != RT_OK) return rc;
+            tum_->bind_upload_buffers(sm, sf);
+        }
         rc = tum_->setup_next_request(*chunks_, [this](int axis, int off, const uint32_t* m, const uint8_t* f) {
             return rt_upload_slice(ctx_, axis, off, m, f);
         });
@@ -141,11 +152,13 @@ int Game::generate_world(uint64_t seed, int region) {
     return RT_OK;
 }
 
-int Game::set_world(const uint32_t* materials, const uint8_t* minefield) {
+int Game::set_world(const uint32_t* materials, const uint8_t* minefield, int region) {
     if (!materials || !minefield) return RT_ERR_INVALID_ARG;
-    materials_.assign(materials, materials + world::kRegionVolume);
-    minefield_.assign(minefield, minefield + world::kRegionVolume);
-    region_ = world::kRegion;
+    if (region != 256 && region != 512 && region != 1024) return RT_ERR_INVALID_ARG;
+    const size_t n = (size_t)region * region * region;
+    materials_.assign(materials, materials + n);
+    minefield_.assign(minefield, minefield + n);
+    region_ = region;
     return RT_OK;
 }
 

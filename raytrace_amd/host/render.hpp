@@ -39,7 +39,7 @@ class Game {
     float get_sun_angle() const { return sun_angle; }                // mod.rs:123-125
     int generate_world(uint64_t seed, int region = RT_ROOT_BLOCK_SIZE);   // region: 256 = the reference; 512 / 1024 = extension
     int world_region() const { return region_; }
-    int set_world(const uint32_t* materials, const uint8_t* minefield);
+    int set_world(const uint32_t* materials, const uint8_t* minefield, int region = RT_ROOT_BLOCK_SIZE);   // region^3 voxels each
     bool has_world() const { return !materials_.empty(); }
     const uint32_t* world_materials() const { return materials_.data(); }
     const uint8_t* world_minefield() const { return minefield_.data(); }

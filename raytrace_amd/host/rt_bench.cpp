@@ -13,9 +13,11 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -57,6 +59,23 @@ RtConfig make_config(int width, int height, int spp, int depth, int device, int 
     cfg.flags = flags;
     return cfg;
 }
+
+// the host threads of --gpus N meet here once per frame (C++17 has no std::barrier)
+class ThreadBarrier {
+ public:
+    explicit ThreadBarrier(int n) : n_(n) {}
+    void arrive_and_wait() {
+        std::unique_lock<std::mutex> lk(m_);
+        const unsigned long gen = gen_;
+        if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); return; }
+        cv_.wait(lk, [&] { return gen_ != gen; });
+    }
+ private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int n_, count_ = 0;
+    unsigned long gen_ = 0;
+};
 
 }  // namespace
 
@@ -132,6 +151,7 @@ int main(int argc, char** argv) {
     std::printf("Created in %fs.\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());   // main.rs:13
 
     RingBufferAverage perf(120);                                      // main.rs:16
+    ThreadBarrier frame_barrier(gpus);
     std::atomic<int> failed{0};
     double total_ms = 0.0;
     // one host thread per device; thread 0 keeps the reference's frame-time statistics (main.rs:42-47)
@@ -139,7 +159,7 @@ int main(int argc, char** argv) {
         rt::render::Pipeline* p = pipes[(size_t)g];
         auto frame_timer = std::chrono::steady_clock::now();
         const auto loop_start = frame_timer;
-        for (int f = 0; f < frames && !failed.load(); f++) {
+        for (int f = 0; f < frames; f++) {
             if (g == 0) {
                 auto now = std::chrono::steady_clock::now();
                 double millis = std::chrono::duration<double, std::milli>(now - frame_timer).count();
@@ -147,12 +167,28 @@ int main(int argc, char** argv) {
                 if (f > 0) perf.push_sample(millis);
             }
             int rc = p->draw_frame(game);                             // main.rs:52
-            if (rc == RT_OK && gather) rc = rt_gather_gbuffer(p->context(), comms[(size_t)g], 0, nullptr, overlap ? 1 : 0);
             if (rc != RT_OK) {
                 std::fprintf(stderr, "frame %d failed on device %d (%d): %s\n", f, devices[(size_t)g], rc, p->last_error());
                 failed.store(1);
             }
+            if (gpus > 1) {
+                // either every rank posts the frame's send/recv or none does: a rank that posted alone would wait for its peers for ever
+                frame_barrier.arrive_and_wait();
+                if (failed.load()) break;
+            } else if (rc != RT_OK) break;
+            if (gather) {
+                rc = rt_gather_gbuffer(p->context(), comms[(size_t)g], 0, nullptr, overlap ? 1 : 0);
+                if (rc != RT_OK) {
+                    // the peers have posted theirs already and cannot be recalled: leave without waiting for them
+                    std::fprintf(stderr, "gather of frame %d failed on device %d (%d): %s\n", f, devices[(size_t)g], rc, p->last_error());
+                    std::fflush(nullptr);
+                    if (gpus > 1) std::_Exit(1);
+                    failed.store(1);
+                    break;
+                }
+            }
         }
+        if (failed.load()) return;     // nothing is waited for on the failure path: queued collectives may have no peer
         if (rt_sync(p->context()) != RT_OK) failed.store(1);
         if (g == 0) total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - loop_start).count();
     };
@@ -162,6 +198,7 @@ int main(int argc, char** argv) {
     for (auto& t : threads) t.join();
 
     int exit_code = failed.load() ? 1 : 0;
+    if (exit_code && gpus > 1) { std::fflush(nullptr); std::_Exit(1); }   // communicators may hold unmatched operations: no orderly teardown
     if (!exit_code) {
         std::printf("%.3fms / %.3fms\n", perf.average(), perf.max());    // main.rs:45-46: average / max
         // a checksum of the assembled frame's depth plane shows that the gather delivered pixels (0 without --gather)

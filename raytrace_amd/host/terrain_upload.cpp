@@ -82,6 +82,8 @@ int TerrainUploadManager::upload_slice(world::ChunkStorage& chunks, const SliceS
     const world::Dims3 cdims{kChunk, kChunk, kChunk};
     long win[3];
     for (int a = 0; a < 3; a++) win[a] = rq.origin[a] * kChunk + (long)rq.num_slices[a] * kSlice;
+    uint32_t* const mat_buf = ext_materials_ ? ext_materials_ : material_upload_buffer_.data();
+    uint8_t* const mine_buf = ext_minefield_ ? ext_minefield_ : minefield_upload_buffer_.data();
     // chunk ranges per axis
     long c0[3], c1[3];
     for (int a = 0; a < 3; a++) {
@@ -105,12 +107,12 @@ int TerrainUploadManager::upload_slice(world::ChunkStorage& chunks, const SliceS
                 if (size[0] <= 0 || size[1] <= 0 || size[2] <= 0) continue;
                 const world::PackedChunkData& pc = chunks.borrow_packed_chunk_data(cx, cy, cz);
                 world::copy_3d({size[0], size[1], size[2]}, pc.materials.data(), cdims, {src[0], src[1], src[2]},
-                               material_upload_buffer_.data(), shape, {dst[0], dst[1], dst[2]});
+                               mat_buf, shape, {dst[0], dst[1], dst[2]});
                 world::copy_3d({size[0], size[1], size[2]}, pc.minefield.data(), cdims, {src[0], src[1], src[2]},
-                               minefield_upload_buffer_.data(), shape, {dst[0], dst[1], dst[2]});
+                               mine_buf, shape, {dst[0], dst[1], dst[2]});
             }
     const int axis_offset = rq.num_slices[m] * kSlice;          // :224-230
-    int rc = sink(m, axis_offset, material_upload_buffer_.data(), minefield_upload_buffer_.data());
+    int rc = sink(m, axis_offset, mat_buf, mine_buf);
     if (rc == RT_OK) gpu_position_ = rq.new_position;           // :273
     return rc;
 }

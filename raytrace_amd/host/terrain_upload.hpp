@@ -37,6 +37,10 @@ class TerrainUploadManager {
     // Returns RT_OK (also when the queue is empty) or the sink's error.
     int setup_next_request(world::ChunkStorage& chunks, const SliceSink& sink);
     void get_render_offset(long out[3]) const { gpu_position_.render_offset(out); }   // :285-287
+    // The reference's upload buffers are host-visible mapped device buffers (:65-82) that upload_slice fills in place; a host
+    // that has such memory (rt_slice_staging: pinned) binds it here for the NEXT request, otherwise the slab is built in the
+    // manager's own vectors.  Each must hold 16 * R * R elements.
+    void bind_upload_buffers(uint32_t* materials, uint8_t* minefield) { ext_materials_ = materials; ext_minefield_ = minefield; }
     size_t pending() const { return queue_.size(); }
     const Position& cpu_position() const { return cpu_position_; }
 
@@ -48,6 +52,8 @@ class TerrainUploadManager {
     Position cpu_position_, gpu_position_;
     std::vector<uint32_t> material_upload_buffer_;   // one slab: 16 x R x R (:65-82)
     std::vector<uint8_t> minefield_upload_buffer_;
+    uint32_t* ext_materials_ = nullptr;
+    uint8_t* ext_minefield_ = nullptr;
 };
 
 }  // namespace rt::render

@@ -90,6 +90,16 @@ class Context:
             raise ValueError("world arrays must hold region^3 voxels")
         self._check(self._lib.rt_upload_world(self._h, _p(materials), _p(minefield)))
 
+    def slice_staging(self):
+        """rt_slice_staging: (materials u32[16 R^2], minefield u8[16 R^2]) views of the library's pinned slab staging — fill them
+        and pass them to upload_slice to skip the copy into the staging buffer."""
+        pm, pf = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.rt_slice_staging(self._h, C.byref(pm), C.byref(pf)))
+        n = 16 * (self.cfg.region if self.cfg is not None else 256) ** 2
+        mats = np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint32)), shape=(n,))
+        mine = np.ctypeslib.as_array(C.cast(pf, C.POINTER(C.c_uint8)), shape=(n,))
+        return mats, mine
+
     def upload_slice(self, axis, texel_offset, materials, minefield):
         materials = np.ascontiguousarray(materials, dtype=np.uint32).reshape(-1)
         minefield = np.ascontiguousarray(minefield, dtype=np.uint8).reshape(-1)
@@ -295,13 +305,14 @@ class Game:
     def set_sun_angle(self, a):
         _lib.host().rth_game_set_sun_angle(self._h, float(a))
 
-    def set_world(self, materials, minefield):
+    def set_world(self, materials, minefield, region=256):
         materials = np.ascontiguousarray(materials, dtype=np.uint32).reshape(-1)
         minefield = np.ascontiguousarray(minefield, dtype=np.uint8).reshape(-1)
-        assert materials.size == 256 ** 3 and minefield.size == 256 ** 3
-        rc = _lib.host().rth_game_set_world(self._h, _p(materials), _p(minefield))
+        if materials.size != region ** 3 or minefield.size != region ** 3:
+            raise ValueError("world arrays must hold region^3 voxels")
+        rc = _lib.host().rth_game_set_world_r(self._h, _p(materials), _p(minefield), int(region))
         if rc != 0:
-            raise RtError(rc, "set_world")
+            raise RtError(rc, "set_world: region must be 256, 512 or 1024")
 
     def generate_world(self, seed=0x5EED, region=256):
         rc = _lib.host().rth_game_generate_world_r(self._h, C.c_uint64(int(seed)), int(region))

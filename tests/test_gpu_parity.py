@@ -255,7 +255,9 @@ def test_pipeline_mirror_draw_frame(blue_noise):
 def test_upload_slice_matches_full_upload(procedural_region, blue_noise, region, flags):
     """rt_upload_slice (terrain_upload.rs:84-275): patching 16-thick slabs on each axis — terrain of another seed, so mixed
     bricks, materials and every minefield value move — equals uploading the edited region; the slab path re-tiles only the
-    slab (any region size).  A slab with a minefield value above 30 is rejected and leaves no drawable world."""
+    slab (any region size); slabs assembled in the library's pinned staging (rt_slice_staging) take the same path without the
+    staging copy.  A slab with a minefield value above 30 is rejected BEFORE it is applied: the region stays as it was and stays
+    drawable — also after two rejections in a row (the second used to hide the first)."""
     if region == 256:
         mats, mine = procedural_region
         origin = (-20.0, -120.0, 60.0)
@@ -276,10 +278,16 @@ def test_upload_slice_matches_full_upload(procedural_region, blue_noise, region,
     with render.Context(cfg) as ctx:
         ctx.upload_world(mats, mine)
         ctx.upload_noise(blue_noise)
-        for axis, off in edits:
+        for k, (axis, off) in enumerate(edits):
             sl = [slice(None)] * 3
             sl[2 - axis] = slice(off, off + 16)
-            ctx.upload_slice(axis, off, np.ascontiguousarray(mats2[tuple(sl)]), np.ascontiguousarray(mine2[tuple(sl)]))
+            if k % 2 == 0:
+                ctx.upload_slice(axis, off, np.ascontiguousarray(mats2[tuple(sl)]), np.ascontiguousarray(mine2[tuple(sl)]))
+            else:       # assembled in place in the pinned staging buffers
+                sm, sf = ctx.slice_staging()
+                sm[:] = mats2[tuple(sl)].reshape(-1)
+                sf[:] = mine2[tuple(sl)].reshape(-1)
+                ctx.upload_slice(axis, off, sm, sf)
         ctx.draw_frame(u)
         ctx.sync()
         a = ctx.readback_all()
@@ -290,16 +298,22 @@ def test_upload_slice_matches_full_upload(procedural_region, blue_noise, region,
         if not flags & abi.RT_FLAG_TRUSTED_WORLD:
             bad = np.full(16 * R * R, 6, np.uint8)
             bad[12345] = 31
+            def same_frame():
+                ctx.draw_frame(u)
+                ctx.sync()
+                b = ctx.readback_all()
+                for name in a:
+                    assert np.array_equal(a[name], b[name], equal_nan=True), name
+
+            with pytest.raises(render.RtError) as e:
+                ctx.upload_slice(1, 64, np.zeros(16 * R * R, np.uint32), bad)      # bad A
+            assert e.value.code == abi.RT_ERR_INVALID_ARG and "above 30" in str(e.value)
+            same_frame()                 # rejected before anything was written: the region is intact and drawable
             with pytest.raises(render.RtError):
-                ctx.upload_slice(1, 64, np.zeros(16 * R * R, np.uint32), bad)
-            with pytest.raises(render.RtError):
-                ctx.draw_frame(u)            # the region holds a rejected slab: nothing to draw until it is replaced
-            ctx.upload_slice(1, 64, np.ascontiguousarray(mats2[:, 64:80, :]), np.ascontiguousarray(mine2[:, 64:80, :]))
-            ctx.draw_frame(u)
-            ctx.sync()
-            b = ctx.readback_all()
-            for name in a:
-                assert np.array_equal(a[name], b[name], equal_nan=True), name
+                ctx.upload_slice(2, 32, np.zeros(16 * R * R, np.uint32), bad)      # bad B
+            same_frame()
+            ctx.upload_slice(2, 32, np.ascontiguousarray(mats2[32:48, :, :]), np.ascontiguousarray(mine2[32:48, :, :]))   # good B (unchanged content)
+            same_frame()                 # ... and A's values never reached the region
     cpu, _ = po.render(mats2, mine2, blue_noise, u, 64, 64, 1, 2, region=region)
     for name in cpu:
         assert np.array_equal(a[name], cpu[name], equal_nan=True), name

@@ -55,3 +55,14 @@ def test_create_instance_without_gpu_reports_the_error(blue_noise):
     with pytest.raises(render.RtError) as e:
         render.create_instance(render.make_config(32, 32), g, blue_noise)
     assert "rt_create" in str(e.value)
+
+
+def test_create_instance_never_replaces_a_world_the_caller_set(blue_noise):
+    """a world set by the caller used to be regenerated silently when the config's region differed."""
+    g = render.Game()
+    g.set_world(np.zeros(256 ** 3, dtype=np.uint32), np.full(256 ** 3, 6, dtype=np.uint8))
+    with pytest.raises(render.RtError) as e:
+        render.create_instance(render.make_config(32, 32, region=512), g, blue_noise)
+    assert "region 256" in str(e.value) and "512" in str(e.value)
+    with pytest.raises(ValueError):
+        g.set_world(np.zeros(256 ** 3, dtype=np.uint32), np.full(256 ** 3, 6, dtype=np.uint8), region=512)
