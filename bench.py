@@ -29,8 +29,9 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+COUNTERS_FILE = "r3_counters.json"   # written by tools/pmc_to_json.py on the GPU box (tools/profile_r3.sh)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-KERNEL_NAMES = {"seq": "k_seq", "paths": "k_paths", "persistent": "k_persist", "persistent2": "k_persist2", "wavefront": "k_trace", "mega": "k_mega"}
+KERNEL_NAMES = {"seq": "k_seq", "paths": "k_paths", "persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}
 
 
 def parse_args():
@@ -45,7 +46,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1, help="seed of the frame's first sample (pipeline.rs:201 starts at 1)")
     ap.add_argument("--vary-seed", action="store_true",
                     help="frame i is drawn with seed + i (every step renders a different frame; the hash is the last one's)")
-    ap.add_argument("--kernel", choices=["default", "seq", "paths", "persistent", "persistent2", "wavefront", "mega"], default="default")
+    ap.add_argument("--kernel", choices=["default", "seq", "paths", "persistent", "wavefront", "mega"], default="default")
     ap.add_argument("--no-cache-primary", dest="cache_primary", action="store_false",
                     help="re-trace the (seed-independent) primary ray for every sample, like spp reference frames would")
     ap.set_defaults(cache_primary=True)
@@ -96,7 +97,7 @@ def kernel_source_sha16():
 def profile_record(kernel, workload_key):
     """Counters of the dominant kernel from the committed rocprofv3 runs (profiles/r2_counters.json, written by
     tools/pmc_to_json.py on the GPU box): None unless the profile was taken on exactly these kernel sources."""
-    path = os.path.join(ROOT, "profiles", "r2_counters.json")
+    path = os.path.join(ROOT, "profiles", COUNTERS_FILE)
     if not os.path.exists(path):
         return None
     try:
@@ -160,7 +161,7 @@ def main():
     reserve_cus = int(os.environ.get("RT_RESERVE_CUS", "0") or 0)
 
     kernel = {"default": abi.RT_KERNEL_DEFAULT, "seq": abi.RT_KERNEL_SEQ, "paths": abi.RT_KERNEL_PATHS, "persistent": abi.RT_KERNEL_PERSISTENT,
-              "persistent2": abi.RT_KERNEL_PERSISTENT2, "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
+              "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
     noise = np.fromfile(os.path.join(ROOT, "tests", "golden", "blue_noise_512.rgba"), dtype=np.uint8)
     REGION = args.region
@@ -212,7 +213,7 @@ def main():
         cctx.draw_frame(u0)
         cctx.sync()
         # the report names the kernel the frame actually ran on (RT_KERNEL_DEFAULT picks k_paths / k_persist per frame)
-        rec["kernel"] = {abi.RT_KERNEL_SEQ: "seq", abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent", abi.RT_KERNEL_PERSISTENT2: "persistent2",
+        rec["kernel"] = {abi.RT_KERNEL_SEQ: "seq", abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent",
                          abi.RT_KERNEL_WAVEFRONT: "wavefront", abi.RT_KERNEL_MEGA: "mega"}[cctx.kernel_in_use()]
         cn = cctx.counters()
         cctx.destroy()
@@ -221,7 +222,7 @@ def main():
         rec["trace_bytes"] = cn.minefield_fetches + 4 * cn.material_fetches
         rec["balg"] = cn.algorithmic_bytes()
         rec["ref_rays"] = cn.rays + (SPP - 1) * cn.pixels if args.cache_primary else cn.rays
-        if rec["kernel"] in ("seq", "paths", "persistent", "persistent2") and args.cache_primary and D >= 1:
+        if rec["kernel"] in ("seq", "paths", "persistent") and args.cache_primary and D >= 1:
             # the dominant kernel walks only shadow/diffuse rays; the primary prepass (k_primary2) is a separate launch,
             # untimed for the roofline: subtract its share, measured with a depth-0 counting frame
             c0 = make_ctx(abi.RT_FLAG_COUNTERS, depth=0)
@@ -232,6 +233,9 @@ def main():
             rec["trace_bytes"] -= cn0.minefield_fetches + 4 * cn0.material_fetches
 
         ctx = make_ctx(abi.RT_FLAG_TIMING)      # renders on the context's own stream; so does rt_gather_gbuffer
+        inf = ctx.info()
+        rec["samples_per_launch"], rec["light_record_bytes"], rec["light_budget_bytes"] = inf.samples_per_launch, inf.light_record_bytes, inf.light_record_budget_bytes
+        rec["device_bytes"] = inf.device_bytes
         frames = None
         if dist_on and rank == 0:
             frames = {b: torch.empty(W * H * bpp[b], dtype=torch.uint8, device=dev) for b in gather_ids}
@@ -304,9 +308,49 @@ def main():
             dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
             dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         rec["elapsed_max"] = float(t_all.item())
+        # per-rank spread (the elapsed time ends at a barrier and is the same everywhere; the path kernels' own time and the
+        # ray counts are what differ between ranks): [min, max] over the ranks
+        spread = torch.tensor([rec["trace_ms"], -rec["trace_ms"], float(rec["rays"]), -float(rec["rays"])], dtype=torch.float64, device=rdev)
+        if dist_on:
+            dist.all_reduce(spread, op=dist.ReduceOp.MAX)
+        sp = [float(x) for x in spread.tolist()]
+        rec["rank_trace_ms"] = [-sp[1], sp[0]]
+        rec["rank_rays"] = [int(-sp[3]), int(sp[2])]
         rec["rays_total"], rec["trace_bytes_total"], rec["balg_total"], rec["ref_rays_total"] = [float(x) for x in sums.tolist()]
         rec["sha"] = sha
         return rec
+
+    def roofline_of(r, steps, W_, H_, SPP_, D_):
+        """Roofline record of the dominant kernel on THIS rank: algorithmic bytes of its launches / their duration (HIP events on
+        the stream the kernel runs on).  Fabric/HBM bytes and SQ counters come from the committed rocprofv3 passes of the same
+        command (separate --pmc runs cannot share a process with the timed run); they are attached only when taken on exactly
+        these kernel sources and — being whole-frame figures — only at N = 1."""
+        kname = KERNEL_NAMES[r["kernel"]]
+        launches_per_frame = r["trace_launches"] // max(steps, 1)
+        avg_launch_ms = r["trace_ms"] / max(r["trace_launches"], 1)
+        achieved = (r["trace_bytes"] * steps) / (r["trace_ms"] * 1e-3) / 1e9 if r["trace_ms"] > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "launches_per_frame": launches_per_frame, "avg_launch_ms": round(avg_launch_ms, 4),
+                    "algorithmic_bytes_per_launch": int(r["trace_bytes"] / max(launches_per_frame, 1)),
+                    "samples_per_launch": int(r["samples_per_launch"])}
+        if world > 1:
+            roofline["rank"] = 0
+            roofline["ranks_path_kernel_ms_per_frame"] = {"min": round(r["rank_trace_ms"][0] / max(steps, 1), 4), "max": round(r["rank_trace_ms"][1] / max(steps, 1), 4)}
+            roofline["ranks_rays_per_frame"] = {"min": r["rank_rays"][0], "max": r["rank_rays"][1]}
+        wkey = "%dx%d spp=%d depth=%d region=%d" % (W_, H_, SPP_, D_, REGION)
+        prof = profile_record(kname, wkey) if world == 1 else None
+        if prof:
+            roofline["traffic"] = prof.get("hbm_bytes_per_launch")
+            roofline["traffic_source"] = ("profiles/%s: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (separate --pmc "
+                                          "passes of this command, taken on kernel sources %s)" % (COUNTERS_FILE, kernel_source_sha16()))
+            if prof.get("hbm_bytes_per_launch") and avg_launch_ms > 0:
+                gbs = prof["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
+                roofline["measured_hbm"] = {"GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
+                                            "bytes_per_launch": prof["hbm_bytes_per_launch"], "l2_hit_rate": prof.get("l2_hit_rate")}
+            if "valu" in prof:
+                roofline["valu"] = prof["valu"]
+        return roofline
 
     W, H, SPP, D = args.width, args.height, args.spp, args.depth
     rec = measure(W, H, SPP, D, args.steps, args.warmup)
@@ -317,34 +361,14 @@ def main():
         c4 = {"workload": "3840x2160 spp=256 depth=8", "steps": 3, "warmup": 1, "ms_per_step": round(r4["elapsed_max"] / 3 * 1e3, 3),
               "value": round(r4["rays_total"] * 3 / r4["elapsed_max"] / 1e6, 2), "unit": "Mrays/s", "rays_per_frame": int(r4["rays_total"]),
               "frame_sha256_16": r4["sha"]}
+        if rank == 0:
+            c4["roofline"] = roofline_of(r4, 3, 3840, 2160, 256, 8)
 
     if rank == 0:
         elapsed = rec["elapsed_max"]
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rec["rays_total"] * args.steps / elapsed / 1e6
-        kname = KERNEL_NAMES[rec["kernel"]]
-        launches_per_frame = rec["trace_launches"] // max(args.steps, 1)
-        avg_launch_ms = rec["trace_ms"] / max(rec["trace_launches"], 1)
-        # roofline of the dominant kernel on this rank: algorithmic bytes of its launches / their duration (HIP events)
-        achieved = (rec["trace_bytes"] * args.steps) / (rec["trace_ms"] * 1e-3) / 1e9 if rec["trace_ms"] > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "launches_per_frame": launches_per_frame, "avg_launch_ms": round(avg_launch_ms, 4),
-                    "algorithmic_bytes_per_launch": int(rec["trace_bytes"] / max(launches_per_frame, 1))}
-        # HBM-side bytes and SQ counters come from the committed rocprofv3 passes of this same command (separate --pmc runs
-        # cannot share a process with the timed run); they are attached only when taken on exactly these kernel sources
-        wkey = "%dx%d spp=%d depth=%d region=%d" % (W, H, SPP, D, REGION)
-        prof = profile_record(kname, wkey) if world == 1 else None
-        if prof:
-            roofline["traffic"] = prof.get("hbm_bytes_per_launch")
-            roofline["traffic_source"] = ("profiles/r2_counters.json: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (separate --pmc "
-                                          "passes of this command, taken on kernel sources %s)" % kernel_source_sha16())
-            if prof.get("hbm_bytes_per_launch") and avg_launch_ms > 0:
-                gbs = prof["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9
-                roofline["measured_hbm"] = {"GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
-                                            "bytes_per_launch": prof["hbm_bytes_per_launch"], "l2_hit_rate": prof.get("l2_hit_rate")}
-            if "valu" in prof:
-                roofline["valu"] = prof["valu"]
+        roofline = roofline_of(rec, args.steps, W, H, SPP, D)
         out = {
             "metric": "Mrays/s at %dx%d spp=%d (rays actually traced: primary + shadow + diffuse)" % (W, H, SPP),
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -359,13 +383,19 @@ def main():
                        "gather": None if not dist_on else (("rt_gather_gbuffer over RCCL, " + ("overlapped with the next frame" if overlap
                                                                                               else "serial on the render stream"))
                                                            if rccl else "host-staged (%s rehearsal)" % backend),
-                       "reserve_cus": reserve_cus},
+                       "reserve_cus": reserve_cus,
+                       # footprint of rank 0's context: samples one path-kernel launch covers and what its light records take
+                       # (sized for min(16 GiB, a tenth of the free memory) unless RT_PERSIST_LIGHT_GIB says otherwise)
+                       "samples_per_launch": int(rec["samples_per_launch"]), "light_record_bytes": int(rec["light_record_bytes"]),
+                       "light_record_budget_bytes": int(rec["light_budget_bytes"]), "context_device_bytes": int(rec["device_bytes"])},
             "roofline": roofline,
         }
         if c4 is not None:
             out["c4"] = c4
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mats, mine, noise, uniforms(args.seed), W, H, SPP, D, int(rec["rays_total"]), region=REGION)
+        if not args.no_cpu_baseline:
+            # rank 0's host cores, after the timed region (the other ranks wait at the closing barrier); a shorter sample at N > 1
+            out["cpu_baseline"] = cpu_baseline(mats, mine, noise, uniforms(args.seed), W, H, SPP, D, int(rec["rays_total"]),
+                                               target_s=12.0 if world == 1 else 6.0, region=REGION)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -97,8 +97,7 @@ typedef enum RtKernel {
     RT_KERNEL_PERSISTENT = 3, /* production kernel: persistent wave64 path kernel, a lane owns a path with its shadow
                                  and diffuse ray in two ray slots, state in registers, __ballot batched transitions,
                                  nibble map in LDS, per-XCD path cursors                                         */
-    RT_KERNEL_PERSISTENT2 = 4,/* same machinery, but a lane carries TWO paths, each walking its shadow ray then its
-                                 diffuse ray in one slot (fuller waves, heavier transitions)        */
+    /* 4 was RT_KERNEL_PERSISTENT2 (two paths per lane, one slot each): retired in round 3, rejected by rt_create */
     RT_KERNEL_PATHS = 5,      /* a lane carries two paths with two ray slots each (four fetch chains in flight per lane) and
                                  the step loop is branch-free; frames it does not cover (no primary cache)
                                  run on RT_KERNEL_PERSISTENT                                                     */
@@ -188,6 +187,18 @@ typedef struct RtTiming {
 
 typedef struct RtContext RtContext;
 
+/* What a context allocated (no reference counterpart: Vulkan reports this through the allocator's own statistics). */
+typedef struct RtInfo {
+    uint32_t struct_size;               /* = sizeof(RtInfo), set by the caller                                              */
+    int32_t  num_cus;                   /* CUs the persistent kernels launch on (RT_RESERVE_CUS subtracted)                 */
+    uint32_t samples_per_launch;        /* samples of every pixel one path-kernel launch covers (spp / this = launches)     */
+    uint32_t reserved;
+    uint64_t light_record_budget_bytes; /* what the per-path light records were sized for: min(16 GiB, free / 10) or
+                                           RT_PERSIST_LIGHT_GIB                                                            */
+    uint64_t light_record_bytes;        /* ... and what they take                                                          */
+    uint64_t device_bytes;              /* all device memory the context holds                                             */
+} RtInfo;
+
 /* render::create_instance (src/render/mod.rs:36-43) + Pipeline::new (pipeline.rs:36-76):
  * create device resources for one GPU. *out is NULL on failure; rt_last_error(NULL) explains. */
 int rt_create(const RtConfig* cfg, RtContext** out);
@@ -223,6 +234,9 @@ int rt_upload_slice(RtContext* ctx, int axis, int texel_offset,
  * buffer.  The memory is the host's to write from the return of this call until its next rt_upload_slice (the call waits
  * until the previous slab's transfer has left the buffer); it lives as long as the context. */
 int rt_slice_staging(RtContext* ctx, uint32_t** materials, uint8_t** minefield);
+
+/* Allocation figures of the context (see RtInfo). */
+int rt_get_info(RtContext* ctx, RtInfo* out);
 
 /* Blue-noise table (render_data.rs:110-133; decoded by structures.rs:496-517): RGBA8 512x512. */
 int rt_upload_noise(RtContext* ctx, const uint8_t* rgba8);

@@ -3,7 +3,7 @@ import fails loudly (build it with `python -m raytrace_amd.build`)."""
 import ctypes as C
 import os
 
-from .abi import RtConfig, RtCounters, RtTiming, RtUniforms
+from .abi import RtConfig, RtCounters, RtInfo, RtTiming, RtUniforms
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_AMD_LIB: load another build of the same library (same-box A/B timing of two kernel variants, tools/ab.sh)
@@ -18,7 +18,7 @@ ABI_SYMBOLS = (
     "rt_untile_gbuffer", "rt_denoise", "rt_finalize", "rt_denoise_planes", "rt_finalize_planes", "rt_kernel_in_use", "rt_get_counters", "rt_reset_counters", "rt_get_timing",
     "rt_abi_version",
     "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_gather_gbuffer", "rt_frame_ptr",
-    "rt_frame_readback", "rt_selftest",
+    "rt_frame_readback", "rt_selftest", "rt_get_info",
 )
 
 _amd = None
@@ -77,6 +77,8 @@ def amd():
         lib.rt_get_counters.argtypes = [P, C.POINTER(RtCounters)]
         lib.rt_reset_counters.argtypes = [P]
         lib.rt_get_timing.argtypes = [P, C.POINTER(RtTiming)]
+        lib.rt_get_info.argtypes = [P, C.POINTER(RtInfo)]
+        lib.rt_get_info.restype = C.c_int
         lib.rt_abi_version.restype = C.c_uint32
         lib.rt_comm_unique_id.argtypes = [P, C.c_size_t]
         lib.rt_comm_init_rank.argtypes = [P, P, C.c_size_t, C.POINTER(P)]

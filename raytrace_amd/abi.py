@@ -20,7 +20,7 @@ RT_ERR_UNIMPLEMENTED = -5
 RT_ERR_OOM = -6
 
 RT_FLAG_TRUSTED_WORLD = 0x10
-RT_KERNEL_DEFAULT, RT_KERNEL_MEGA, RT_KERNEL_WAVEFRONT, RT_KERNEL_PERSISTENT, RT_KERNEL_PERSISTENT2, RT_KERNEL_PATHS, RT_KERNEL_SEQ = 0, 1, 2, 3, 4, 5, 6
+RT_KERNEL_DEFAULT, RT_KERNEL_MEGA, RT_KERNEL_WAVEFRONT, RT_KERNEL_PERSISTENT, RT_KERNEL_PATHS, RT_KERNEL_SEQ = 0, 1, 2, 3, 5, 6   # 4: retired
 RT_FLAG_COUNTERS = 0x1
 RT_FLAG_CACHE_PRIMARY = 0x2
 RT_FLAG_TIMING = 0x4
@@ -91,6 +91,11 @@ class RtCounters(C.Structure):
     def algorithmic_bytes(self):
         """B_alg of SURVEY.md 8(d) / BASELINE.md 5."""
         return self.minefield_fetches + 4 * self.material_fetches + 4 * self.noise_fetches + 23 * self.pixels
+
+
+class RtInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("num_cus", C.c_int32), ("samples_per_launch", C.c_uint32), ("reserved", C.c_uint32),
+                ("light_record_budget_bytes", C.c_uint64), ("light_record_bytes", C.c_uint64), ("device_bytes", C.c_uint64)]
 
 
 class RtTiming(C.Structure):

@@ -43,7 +43,7 @@ struct RtContext {
     bool world_resident = false;          // a full region has been uploaded once (slabs may patch it)
 
     // scene
-    uint8_t* d_mine_lin = nullptr; uint32_t* d_mat_lin = nullptr;
+    // (the caller-layout copy of the region exists only inside rt_upload_world: 5 B/voxel, 5 GiB at R = 1024)
     uint8_t* d_mine_sw = nullptr; uint32_t* d_mat_sw = nullptr;
     uint32_t* d_coarse = nullptr; uint32_t* d_noise = nullptr; uint32_t* d_flag = nullptr;
     // rt_upload_slice: one 16-thick slab travels pinned host staging -> device staging (own stream) -> re-tile (render stream)
@@ -92,7 +92,7 @@ struct RtContext {
     uint32_t persist_batch = 1;
     uint32_t persist_chunk = 0;   // RT_PERSIST_CHUNK: paths per cursor atomic (multiple of 64); 0 = automatic
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
-    int persist_version = 1;      // 1 = k_persist, 2 = k_persist2 (RT_KERNEL_PERSISTENT2), 3 = k_paths (RT_KERNEL_PATHS)
+    int persist_version = 1;      // 1 = k_persist, 3 = k_paths (RT_KERNEL_PATHS), 4 = k_seq (RT_KERNEL_SEQ)
     int seq_nc = 2;               // k_seq: paths per lane (RT_SEQ_NC; 2 measured faster than 3)
     bool paths_by_size = false;   // RT_KERNEL_DEFAULT: k_paths for launches with enough work, k_persist for small ones
     int last_path_kernel = 0;     // RtKernel the most recent frame's path launches ran on (0 = no frame yet)
@@ -123,6 +123,8 @@ struct RtContext {
     uint32_t timer_overflow = 0;   // launches that found the event pool full (RT_FLAG_TIMING without rt_get_timing)
 
     std::vector<void*> allocs;
+    uint64_t device_bytes = 0;       // sum of the context's device allocations (rt_get_info)
+    uint64_t light_budget_bytes = 0; // what the per-path light records were sized for
 };
 
 constexpr size_t kMaxTimerEvents = 2 * 4096;   // LaunchTimer pool cap: pairs beyond it are not timed (counted in timer_overflow)
@@ -147,7 +149,7 @@ hipError_t dev_alloc(RtContext* c, T** p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
     hipError_t e = hipMalloc((void**)p, count * sizeof(T));
-    if (e == hipSuccess) c->allocs.push_back((void*)*p);
+    if (e == hipSuccess) { c->allocs.push_back((void*)*p); c->device_bytes += count * sizeof(T); }
     return e;
 }
 
@@ -225,9 +227,9 @@ struct LaunchTimer {
     ~LaunchTimer() { if (on) (void)hipEventRecord(c->ev_pool[idx + 1], c->stream); }
 };
 
-int reflatten(RtContext* c) {
+int reflatten(RtContext* c, const uint8_t* d_mine_lin, const uint32_t* d_mat_lin) {
     RT_HIP(c, hipMemsetAsync(c->d_flag, 0, sizeof(uint32_t), c->stream));
-    RT_HIP(c, rtd::launch_flatten(c->d_mine_lin, c->d_mat_lin, c->d_mine_sw, c->d_mat_sw, c->d_coarse, c->d_flag, c->logr, c->stream));
+    RT_HIP(c, rtd::launch_flatten(d_mine_lin, d_mat_lin, c->d_mine_sw, c->d_mat_sw, c->d_coarse, c->d_flag, c->logr, c->stream));
     uint32_t flag = 0;
     RT_HIP(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -303,7 +305,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (cfg->depth < 0 || cfg->depth > RT_MAX_DEPTH) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: depth out of range");
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: bad tile_rank/tile_world");
-    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_SEQ)
+    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_SEQ || cfg->kernel == 4 /* RT_KERNEL_PERSISTENT2, retired */)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown kernel");
 
     int ndev = 0;
@@ -329,7 +331,6 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         // cover run on k_persist (rt_draw_frame decides per frame: lr is a per-frame uniform)
         c->paths_by_size = cfg->kernel == RT_KERNEL_DEFAULT;
         c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PATHS : cfg->kernel;
-        if (c->kernel == RT_KERNEL_PERSISTENT2) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 2; }   // same pipeline, other path kernel
         if (c->kernel == RT_KERNEL_PATHS) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 3; }
         if (c->kernel == RT_KERNEL_SEQ) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 4; }
         if (const char* s = getenv("RT_SEQ_NC")) { int v = atoi(s); if (v == 2 || v == 3) c->seq_nc = v; }
@@ -356,7 +357,6 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     c->plane_pixels = cfg->tile_world == 1 ? (size_t)cfg->width * cfg->height : (size_t)c->tile_capacity * 64;
 
     // scene
-    RT_HIP_CREATE(dev_alloc(c, &c->d_mine_lin, c->vox)); RT_HIP_CREATE(dev_alloc(c, &c->d_mat_lin, c->vox));
     RT_HIP_CREATE(dev_alloc(c, &c->d_mine_sw, c->vox)); RT_HIP_CREATE(dev_alloc(c, &c->d_mat_sw, c->vox));
     RT_HIP_CREATE(dev_alloc(c, &c->d_coarse, (size_t)rtd::kCoarseWords));
     RT_HIP_CREATE(dev_alloc(c, &c->d_noise, (size_t)RT_NOISE_SIZE * RT_NOISE_SIZE));
@@ -391,7 +391,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_PERSIST_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= 4096) c->persist_chunk = (uint32_t)v & ~63u; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
     if (c->persist_threshold == 0)   // measured optima (k_paths: 32 lanes with a parked context, three steps between looks: 24 4.46 ms, 32 4.39, 36 4.39-4.41, 40 4.43, 44 4.51)
-        c->persist_threshold = c->persist_version == 2 ? 40u : (c->persist_version == 4 ? 36u : 32u);
+        c->persist_threshold = c->persist_version == 4 ? 36u : 32u;
     if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 16u;   // k_seq: waiting contexts that trigger the re-arm block
     if (c->kernel == RT_KERNEL_PERSISTENT) {
         RT_HIP_CREATE(dev_alloc(c, &c->pcursor, kCursorWords + 1));   // 8 cursor lines + the worklist count
@@ -408,8 +408,15 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
             // (3840x2160 spp 256 depth 8: 114.1 ms per frame with 1 GiB, 109.3 with 2, 107.0 with 4, 105.6 with 8 and beyond;
             // the 1024^3 spp-1024 frame: 158.1 with 2 GiB, 138.7 with 8, 136.1 with 32); halved until the allocation succeeds
             uint64_t np = c->npix_pad ? c->npix_pad : 1;
+            // default: 16 GiB, but never more than a tenth of what is free on the device right now (a context is one tenant of the GPU)
             uint64_t light_bytes = 16ull << 30;
+            {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b / 10u < light_bytes) light_bytes = (uint64_t)free_b / 10u;
+                else (void)hipGetLastError();
+            }
             if (const char* s = getenv("RT_PERSIST_LIGHT_GIB")) { long long v = atoll(s); if (v >= 1 && v <= 128) light_bytes = (uint64_t)v << 30; }
+            c->light_budget_bytes = light_bytes;
             uint64_t B = light_bytes / (sizeof(rtd::PathLight) * np);
             if (B > (1ull << 31) / np) B = (1ull << 31) / np;   // path indices are 32-bit
             if (const char* s = getenv("RT_PERSIST_BATCH")) { long long v = atoll(s); if (v > 0 && (uint64_t)v < B) B = (uint64_t)v; }   // may only lower the bound
@@ -493,11 +500,22 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
     if (!materials || !minefield) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_world: null pointer");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RT_HIP(ctx, hipMemcpy(ctx->d_mat_lin, materials, ctx->vox * sizeof(uint32_t), hipMemcpyHostToDevice));
-    RT_HIP(ctx, hipMemcpy(ctx->d_mine_lin, minefield, ctx->vox, hipMemcpyHostToDevice));
-    ctx->has_world = false;
-    ctx->world_resident = false;
-    int rc = reflatten(ctx);
+    // the caller-layout copy lives for the duration of this call only (it used to stay resident — 160 MiB at
+    // R = 256, 5 GiB at R = 1024 — although nothing but this function reads it)
+    uint32_t* d_mat_lin = nullptr; uint8_t* d_mine_lin = nullptr;
+    hipError_t e = hipMalloc((void**)&d_mat_lin, ctx->vox * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_mine_lin, ctx->vox);
+    if (e == hipSuccess) e = hipMemcpy(d_mat_lin, materials, ctx->vox * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_mine_lin, minefield, ctx->vox, hipMemcpyHostToDevice);
+    int rc = RT_OK;
+    if (e != hipSuccess) rc = fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, std::string("rt_upload_world: ") + hipGetErrorString(e));
+    else {
+        ctx->has_world = false;
+        ctx->world_resident = false;
+        rc = reflatten(ctx, d_mine_lin, d_mat_lin);      // synchronises the stream before it returns
+    }
+    if (d_mat_lin) (void)hipFree(d_mat_lin);
+    if (d_mine_lin) (void)hipFree(d_mine_lin);
     if (rc != RT_OK) return rc;
     ctx->has_world = true;
     ctx->world_resident = true;
@@ -652,10 +670,10 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                         ctx->last_path_kernel = RT_KERNEL_PATHS;
                         e = rtd::launch_paths(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->num_cus, ctx->stream);
                     } else {
-                        ctx->last_path_kernel = ctx->persist_version == 2 ? RT_KERNEL_PERSISTENT2 : RT_KERNEL_PERSISTENT;
+                        ctx->last_path_kernel = RT_KERNEL_PERSISTENT;
                     }
-                    if (ctx->last_path_kernel == RT_KERNEL_PERSISTENT || ctx->last_path_kernel == RT_KERNEL_PERSISTENT2)
-                        e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, ctx->persist_version == 2 ? 2 : 1, ctx->num_cus, ctx->stream);
+                    if (ctx->last_path_kernel == RT_KERNEL_PERSISTENT)
+                        e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, 1, ctx->num_cus, ctx->stream);
                 }
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 1);
@@ -979,10 +997,20 @@ int rt_frame_readback(RtContext* ctx, int id, void* dst, size_t bytes) {
     return RT_OK;
 }
 
+int rt_get_info(RtContext* ctx, RtInfo* out) {
+    if (!ctx || !out) return RT_ERR_INVALID_ARG;
+    if (out->struct_size != sizeof(RtInfo)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_get_info: RtInfo.struct_size mismatch");
+    out->num_cus = ctx->num_cus;
+    out->samples_per_launch = ctx->kernel == RT_KERNEL_PERSISTENT ? ctx->persist_batch : ctx->batch_samples;
+    out->light_record_budget_bytes = ctx->light_budget_bytes;
+    out->light_record_bytes = ctx->kernel == RT_KERNEL_PERSISTENT ? (uint64_t)sizeof(rtd::PathLight) * (ctx->npix_pad ? ctx->npix_pad : 1) * ctx->persist_batch : 0;
+    out->device_bytes = ctx->device_bytes;
+    return RT_OK;
+}
+
 int rt_kernel_in_use(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->last_path_kernel != 0) return ctx->last_path_kernel;   // what the last frame ran
-    if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 2) return RT_KERNEL_PERSISTENT2;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 3) return RT_KERNEL_PATHS;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 4) return RT_KERNEL_SEQ;
     return ctx->kernel;

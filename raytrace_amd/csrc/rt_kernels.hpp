@@ -66,7 +66,7 @@ struct PersistArgs {
     uint32_t npix_pad;          // CACHE=false: nwork = all local pixels (padded to whole 8x8 tiles)
     uint32_t sample0, nsamples; // samples of this batch: sample0 .. sample0+nsamples-1
     uint32_t threshold;         // parked lanes per wave that trigger a transition pass (1..64)
-    uint32_t rmin;              // k_persist2: contexts waiting for their diffuse ray that trigger the in-loop re-arm block
+    uint32_t rmin;              // k_seq: contexts waiting for their diffuse ray that trigger the in-loop re-arm block
     uint32_t chunk;             // paths per cursor atomic; 0 = the default (128)
     uint32_t nthreads;          // grid size in threads (stride of the albedo stack)
     uint32_t* stack;            // [2][(depth-1)][nthreads] packed material of surface j+1 (only touched when depth >= 2; k_persist uses half)
@@ -87,7 +87,7 @@ hipError_t launch_sky_lut(const Frame& f, float4* dif_lut, hipStream_t st);
 hipError_t launch_primary(const Scene& sc, const Frame& f, const Planes& pl, const PrimaryArgs& a, bool count,
                           int version /* 1 = k_primary, 2 = k_primary2 */, int nworkgroups, hipStream_t st);
 hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, bool cache,
-                          int version /* 1 = k_persist, 2 = k_persist2 */, int nworkgroups, hipStream_t st);
+                          int version /* 1 = k_persist */, int nworkgroups, hipStream_t st);
 
 // k_paths (rt_paths.hip): cached-primary frames with lr = 0 and region 256 only
 hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nworkgroups,

@@ -1,5 +1,5 @@
-// rt_persist.hip — the primary prepass, the direction tables, the ordered accumulation, and round 1's path kernels
-// (k_persist, k_persist2).  The default path kernel of big launches is k_paths (rt_paths.hip); k_persist runs the small ones,
+// rt_persist.hip — the primary prepass, the direction tables, the ordered accumulation, and round 1's path kernel
+// (k_persist).  The default path kernel of big launches is k_paths (rt_paths.hip); k_persist runs the small ones,
 // frames with lr != 0 and frames without the primary cache.
 //
 //   k_primary2 : primary prepass.  One 1024-thread workgroup per CU, nibble map of the scene in LDS; a wave walks whole
@@ -17,8 +17,8 @@
 //                chunk, paths dealt out ballot-ranked) — so shading runs on a well-filled wave and the step loop on
 //                compacted work.  Per path one 12-byte light record goes to HBM; k_accumulate_paths adds a pixel's
 //                samples in order.
-//   k_persist2 : the same machinery regrouped — a lane carries two paths, each walking its level's shadow ray and then
-//                its diffuse ray in one ray slot (rt_dda.hpp); selectable (RT_KERNEL_PERSISTENT2), never the default.
+//   (k_persist2, round 1's regrouping with two paths per lane and one slot each, was retired in round 3: k_paths and k_seq
+//   supersede it on every axis.)
 //
 // The primary ray does not depend on the seed (raytrace.comp:306-320 reads no noise), so with RT_FLAG_CACHE_PRIMARY
 // it is traced once per pixel (prepass) and every sample starts at its first shadow ray.  Without the flag the path
@@ -576,362 +576,6 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
     }
 }
 
-// =====================================================================================================
-// k_persist2 — two paths per lane, one ray slot each
-// =====================================================================================================
-// Same work, same values as k_persist; the grouping differs.  A lane carries TWO paths (contexts A and B).  A context
-// walks the two rays of its level one after the other in its single ray slot — the shadow ray first, then the diffuse
-// ray from the same surface point (its table entry waits in registers) — so a slot is busy for the whole level instead
-// of the shorter ray's slot idling, and the two contexts give the lane the two independent fetch chains k_persist got
-// from its two slots.  A context whose shadow ray ended is re-armed with the diffuse ray by a short block inside the
-// step loop (run when `rmin` contexts wait); a context whose diffuse ray ended parks, and because the lane's other
-// context keeps stepping, the transition pass can wait for a well-filled wave (`threshold` lanes with a parked context)
-// without idling the step loop.  The pass serves one context per lane: lanes whose parked context is B swap A and B
-// first (v_swap_b32), so there is one copy of the pass code.
-enum : uint32_t { P2_EMPTY = 0, P2_PRIMARY = 1, P2_SHADOW = 2, P2_DIF = 3 };
-
-// A path context of k_persist2: its ray slot (RaySlot2, rt_dda.hpp), the level's waiting diffuse ray, the path state.
-struct Ctx2 {
-    RaySlot2 r;
-    // the level's diffuse ray, waiting for the shadow ray to end: table entry (direction, 1/|direction|) in registers, the
-    // first texel (ovox, bit 31 = inside the texture) in a register, the origin in LDS (s_org)
-    float qdx, qdy, qdz, qlx, qly, qlz;
-    uint32_t ovox, ocidx;
-    // path state: st = phase | level << 2 | id << 7 | face id of the level's surface << 8 (id: which of the lane's two
-    // stack / origin areas the context uses);
-    // sn = noise_value texel bytes (r, g) of the path | shadow bits << 16 (bit j-1: shadow ray of level j reached the sky)
-    uint32_t st, item, sn, lp, samp;
-};
-__device__ __forceinline__ uint32_t c2_phase(const Ctx2& c) { return c.st & 3u; }
-__device__ __forceinline__ uint32_t c2_level(const Ctx2& c) { return c.st >> 2 & 31u; }
-__device__ __forceinline__ uint32_t c2_id(const Ctx2& c) { return c.st >> 7 & 1u; }
-__device__ __forceinline__ uint32_t c2_face(const Ctx2& c) { return c.st >> 8 & 7u; }
-__device__ __forceinline__ void c2_set_phase(Ctx2& c, uint32_t ph) { c.st = (c.st & ~3u) | ph; }
-__device__ __forceinline__ bool c2_parks(const Ctx2& c, bool exhausted) {   // parks when its ray has ended
-    const uint32_t ph = c.st & 3u;
-    return ph == P2_DIF || ph == P2_PRIMARY || (ph == P2_EMPTY && !exhausted);
-}
-template <int LOGR, bool LRZ, bool COUNT, bool CACHE>
-__global__ __launch_bounds__(1024, 4) void k_persist2(Scene sc, Frame f, Planes pl, PersistArgs a) {
-    __shared__ uint32_t s_coarse[kCoarseWords];
-    __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
-    __shared__ float s_org[2][3][1024];        // origin of the waiting diffuse ray: [path id][component][thread]
-    __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];   // swizzle tables (rt_dda.hpp)
-    const uint32_t nwork = CACHE ? *a.wl_count : a.npix_pad;
-    const uint32_t nitems = nwork * a.nsamples;
-    if (nitems == 0u) return;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.coarse);
-        uint4* dst = reinterpret_cast<uint4*>(s_coarse);
-        for (uint32_t i = threadIdx.x; i < kCoarseWords / 4; i += 1024u) dst[i] = src[i];
-        if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
-        if (dda_uses_swz<LOGR, LRZ>()) dda_fill_swz(s_swz, threadIdx.x, 1024u);
-    }
-    __syncthreads();
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gtid = blockIdx.x * 1024u + threadIdx.x;
-    const uint32_t threshold = a.threshold, rmin = a.rmin;
-    constexpr int R = 1 << LOGR, LB = LOGR - 2;
-    const float half = (float)R / 2;
-    const uint32_t D = (uint32_t)f.depth;
-    const uint32_t stack_levels = D > 1u ? D - 1u : 1u;
-
-    Ctx2 A, B;
-    {
-        RaySlot2& S = A.r;
-        S.px = S.py = S.pz = S.ndx = S.ndy = S.lx = S.ly = S.lz = S.ux = S.uy = S.uz = 0.0f; S.ndz = -1.0f;
-        S.vox = S.cidx = 0u; S.nk = PX_HIT << 16; S.axis = 2u;
-        S.tracing = false; S.valid = true; S.fresh_invalid = false;
-        A.qdx = A.qdy = A.qlx = A.qly = A.qlz = 0.0f; A.qdz = 1.0f;
-        A.ovox = A.ocidx = 0u;
-        A.st = P2_EMPTY | 7u << 8;   // face id 7: q* hold no table entry yet
-        A.item = A.sn = A.lp = A.samp = 0u;
-        B = A; B.st |= 1u << 7;
-    }
-    bool exhausted = false;
-    // paths per cursor atomic (RT_PERSIST_CHUNK overrides).  Measured with the eight per-XCD cursors: 128 is best or equal from
-    // a 1-sample 1024^2 frame to the spp-64 headline frame; 64 costs 2-3 % there (atomic rate), 256 lengthens small frames' tails
-    const uint32_t kChunk = a.chunk ? a.chunk : 128u;
-    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform: the wave's current chunk of an XCD group's share of the paths
-    uint32_t chunk_sb = 0, chunk_w = 0;       // (sample-in-batch, slot within the share) of path chunk_next
-    uint32_t chunk_w0 = 0, chunk_nw = 1;      // the share's slot range
-    const uint32_t home_grp = blockIdx.x & 7u;   // workgroups b and b + 8 share an XCD (round-robin dispatch; speed only)
-    uint32_t grp_tries = 0;                   // shares found empty so far, starting with the own group's
-
-    unsigned long long c_prim = 0, c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0,
-                       c_noise = 0, c_pix = 0;
-    unsigned long long d_iters = 0, d_sx = 0, d_fx = 0, d_sl = 0, d_fl = 0, d_pass = 0, d_pl = 0, d_sky = 0;   // wave-uniform
-
-    // ---- the ray machinery of rt_dda.hpp bound to this kernel's constants ---------------------------------------------
-    const uint8_t* s_nib = reinterpret_cast<const uint8_t*>(s_coarse);
-    auto advance = [&](RaySlot2& r, uint32_t step) { dda_advance<LOGR, LRZ, COUNT, false>(r, step, f, half, c_border, s_swz); };
-    auto arm = [&](RaySlot2& r, float dx, float dy, float dz, float rox, float roy, float roz, bool ok, uint32_t vox0,
-                   uint32_t cidx0) {   // needs r.l* set
-        dda_arm<LOGR, LRZ, COUNT>(r, dx, dy, dz, rox, roy, roz, ok, vox0, cidx0, f, half, s_nib, sc, c_border, s_swz);
-    };
-    auto tally = [&](const RaySlot2& r) {
-        RayTally t;
-        dda_tally<LOGR>(r, t);
-        c_iter += t.iter; c_hits += t.hits; c_sky += t.sky; c_limit += t.limit; c_border += t.border;
-    };
-    // the shadow ray of a context ended: note its result (:326-328 / :338-340) and start the level's diffuse ray (:330 / :342)
-    auto rearm = [&](Ctx2& c) {
-        if (c2_phase(c) == P2_SHADOW && !c.r.tracing) {
-            if (COUNT) tally(c.r);
-            if (r2_kind(c.r) == PX_AIR) c.sn |= 0x8000u << c2_level(c);   // bit 16 + level - 1
-            c.r.lx = c.qlx; c.r.ly = c.qly; c.r.lz = c.qlz;
-            const uint32_t id = c2_id(c);
-            arm(c.r, c.qdx, c.qdy, c.qdz, s_org[id][0][threadIdx.x], s_org[id][1][threadIdx.x], s_org[id][2][threadIdx.x],
-                (c.ovox >> 31) != 0u, c.ovox & 0x7FFFFFFFu, c.ocidx);
-            c2_set_phase(c, P2_DIF);
-        }
-    };
-
-    // =========================== transition pass ===========================================================
-    // One pass serves ONE of the two contexts of every lane (C = A or B): two instantiations of the same code, so no
-    // register shuffling between the contexts is needed.
-    auto pass = [&](Ctx2& C) {
-        RaySlot2& F = C.r;
-        const uint32_t phaseC = c2_phase(C);
-        const bool mine = !F.tracing && (phaseC == P2_DIF || phaseC == P2_PRIMARY);
-        if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); }
-        bool begin_level = false, need_primary = false;
-        uint32_t new_level = 0;
-        float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
-        uint32_t snormal = 0;
-        if (mine) {
-            // Diffuse / primary result (see k_persist)
-            const uint32_t kind = r2_kind(F);
-            const bool air = kind == PX_AIR;
-            const uint32_t nrm = F.axis == 0 ? (F.ndx < 0.0f ? 1u : 0u) : (F.axis == 1 ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
-            uint32_t material = 0;
-            if (kind == PX_HIT && (LRZ || F.valid)) material = sc.mat[F.vox];
-            float hx = F.px, hy = F.py, hz = F.pz;
-            if (kind == PX_SPECIAL) { hx = hy = hz = __builtin_nanf(""); }
-            const float off = 0.001f;
-            if (nrm == 0) hx += off; else if (nrm == 1) hx -= off;
-            else if (nrm == 2) hy += off; else if (nrm == 3) hy -= off;
-            else if (nrm == 4) hz += off; else hz -= off;
-            if (COUNT) tally(F);
-            bool path_done = false;
-            vec3 light = v3(0, 0, 0);
-            if (!CACHE && phaseC == P2_PRIMARY) {
-                PixelId pix = pixel_of_local(f, C.lp);
-                vec3 pstart, pdir;
-                primary_ray(f, pix.px, pix.py, &pstart, &pdir);
-                if (C.samp == 0u) {
-                    store_primary_planes(pl, pix.out_index, f, pdir, air, nrm, material, v3(hx, hy, hz));
-                    if (COUNT) c_pix++;
-                }
-                if (air) {
-                    light = sample_sky(pdir, ld3(f.sunangle), ld3(f.sunlight), true);               // :321-322
-                    path_done = true;
-                } else if (D < 1u) {
-                    path_done = true;
-                } else {
-                    sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
-                    new_level = 1; C.sn &= 0xFFFFu; begin_level = true;
-                }
-            } else {
-                // a level ended: its shadow result is already in the shadow bits (rearm); now the diffuse result
-                const uint32_t level = c2_level(C), sunbits = C.sn >> 16;
-                if (air || level == D) {
-                    const vec3 sunlight = ld3(f.sunlight);
-                    vec3 sky = v3(0, 0, 0);
-                    if (air) { const float4 t = a.dif_lut[4u * ((c2_face(C) << 16) | (C.sn & 0xFFFFu)) + 3u]; sky = v3(t.x, t.y, t.z); }   // :331-332 / :343-345, tabulated
-                    // L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
-                    vec3 L = v3(0.0f, 0.0f, 0.0f);
-                    if (sunbits >> (level - 1) & 1u) L = vadd(L, sunlight);
-                    if (air) L = vadd(L, sky);
-                    for (uint32_t j = level - 1; j >= 1u; j--) {
-                        const uint32_t pm = a.stack[((size_t)c2_id(C) * stack_levels + (j - 1)) * a.nthreads + gtid];
-                        vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
-                        light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
-                        vec3 acc = v3(0.0f, 0.0f, 0.0f);
-                        if (sunbits >> (j - 1) & 1u) acc = vadd(acc, sunlight);
-                        L = vadd(acc, light2);
-                    }
-                    light = vadd(v3(0.0f, 0.0f, 0.0f), L);
-                    path_done = true;
-                } else {
-                    a.stack[((size_t)c2_id(C) * stack_levels + (level - 1)) * a.nthreads + gtid] = material;   // albedo of surface level+1
-                    sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
-                    new_level = level + 1u; begin_level = true;
-                }
-            }
-            if (path_done) {   // the path's light; k_accumulate_paths adds the samples of a pixel in order
-                a.pl[C.item] = PathLight{light.x, light.y, light.z};
-                c2_set_phase(C, P2_EMPTY);
-            }
-        }
-        // empty contexts pull the next paths (chunked cursor, see k_persist)
-        if (!exhausted) {
-            const bool wantme = c2_phase(C) == P2_EMPTY && !F.tracing;
-            const uint64_t want = __ballot(wantme);
-            const uint32_t nwant = (uint32_t)__popcll(want);
-            if (nwant) {
-                if (chunk_next >= chunk_end) {
-                    // next chunk: from the share of this workgroup's XCD group first (worklist slots [w0, w0 + nw) of every
-                    // sample: one band of the image, so an XCD's L2 keeps seeing the same part of the scene), then from the
-                    // other groups' shares; eight cursor words also lift the ~90 atomics/us limit of a single one
-                    for (;;) {
-                        if (grp_tries == 8u) { exhausted = true; chunk_next = chunk_end = 0u; break; }
-                        const uint32_t g = (home_grp + grp_tries) & 7u;
-                        const uint32_t w0 = (uint32_t)((uint64_t)nwork * g >> 3), nw = (uint32_t)((uint64_t)nwork * (g + 1u) >> 3) - w0;
-                        const uint32_t ng = nw * a.nsamples;
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(a.cursor + 32u * g, kChunk);
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        if (base < ng) {
-                            chunk_next = base; chunk_end = base + kChunk < ng ? base + kChunk : ng;
-                            chunk_w0 = w0; chunk_nw = nw;
-                            chunk_sb = base / nw; chunk_w = base - chunk_sb * nw;   // once per chunk
-                            break;
-                        }
-                        grp_tries++;   // that group's share is handed out for good (its cursor only grows)
-                    }
-                }
-                const uint32_t take = min(nwant, chunk_end - chunk_next);
-                chunk_next += take;
-                if (wantme) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-                    if (rank < take) {
-                        uint32_t sb = chunk_sb, w = chunk_w + rank;
-                        while (w >= chunk_nw) { w -= chunk_nw; sb++; }
-                        w += chunk_w0;   // worklist slot (CACHE) / local pixel
-                        uint32_t wgx8 = 0, wgy8 = 0;
-                        bool ok = true;
-                        if (CACHE) {
-                            const uint32_t info = a.pinfo[w];
-                            sfx = a.phx[w]; sfy = a.phy[w]; sfz = a.phz[w];
-                            snormal = info >> 28; wgx8 = info & 0x3FFFu; wgy8 = (info >> 14) & 0x3FFFu;
-                        } else {
-                            PixelId pix = pixel_of_local(f, w);
-                            ok = pix.inside;           // padding pixels of partial tiles carry no path
-                            wgx8 = owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE;
-                            wgy8 = owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE;
-                        }
-                        if (ok) {
-                            C.st = (C.st & 0x80u) | 7u << 8 | P2_EMPTY;   // face id 7: q* hold no table entry of this path
-                            C.item = sb * nwork + w; C.lp = w; C.samp = a.sample0 + sb;
-                            const uint32_t seed = (f.seed + C.samp) % (uint32_t)RT_NOISE_BYTES;
-                            const uint32_t by = seed / RT_NOISE_SIZE;
-                            const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
-                            const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
-                            C.sn = sc.noise[ty * RT_NOISE_SIZE + tx] & 0xFFFFu;   // noise_value (r, g); no shadow bits yet
-                            if (CACHE) { new_level = 1; begin_level = true; }
-                            else need_primary = true;
-                        }
-                    }
-                }
-                chunk_w += take;
-                while (chunk_w >= chunk_nw) { chunk_w -= chunk_nw; chunk_sb++; }
-            }
-        }
-        // both rays of a level (:324-330 / :336-342): the shadow ray starts now; the diffuse ray's table entry, first texel
-        // and origin wait in the context's q*/ovox registers and in s_org
-        if (begin_level) {
-            if (COUNT) { c_noise++; c_shadow++; c_dif++; }
-            int ix, iy, iz;
-            const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
-            const uint32_t vox0 = swizzled_index(ix, iy, iz, LB), cidx0 = coarse_index(ix, iy, iz, LOGR);
-            const uint32_t se = C.sn & 0xFFFFu;
-            const float4 sd = a.sun_lut[2u * se], sl = a.sun_lut[2u * se + 1u];
-            F.lx = sl.x; F.ly = sl.y; F.lz = sl.z;
-            arm(F, sd.x, sd.y, sd.z, sfx, sfy, sfz, ok, vox0, cidx0);
-            // q* still hold the entry (face, se) of the path's previous level; a new path carries face id 7
-            if (snormal != c2_face(C)) {
-                const uint32_t di = 4u * ((snormal << 16) | se);
-                const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
-                C.qdx = d2.x; C.qdy = d2.y; C.qdz = d2.z; C.qlx = dl.x; C.qly = dl.y; C.qlz = dl.z;
-            }
-            const uint32_t id = c2_id(C);
-            s_org[id][0][threadIdx.x] = sfx; s_org[id][1][threadIdx.x] = sfy; s_org[id][2][threadIdx.x] = sfz;
-            C.ovox = vox0 | (ok ? 0x80000000u : 0u); C.ocidx = cidx0;
-            C.st = P2_SHADOW | new_level << 2 | (C.st & 0x80u) | snormal << 8;
-        }
-        // primary ray of the pixel (:296-315), CACHE=false only
-        if (!CACHE && need_primary) {
-            PixelId pix = pixel_of_local(f, C.lp);
-            vec3 ro, rd;
-            primary_ray(f, pix.px, pix.py, &ro, &rd);
-            int ix, iy, iz;
-            const bool ok = wrap_texel(ro, (float)R, &ix, &iy, &iz);
-            const vec3 d = vnormalize(rd);                                                               // :83
-            F.lx = 1.0f / rtm_abs(d.x); F.ly = 1.0f / rtm_abs(d.y); F.lz = 1.0f / rtm_abs(d.z);           // :88
-            arm(F, d.x, d.y, d.z, ro.x, ro.y, ro.z, ok, swizzled_index(ix, iy, iz, LB), coarse_index(ix, iy, iz, LOGR));
-            c2_set_phase(C, P2_PRIMARY);
-            if (COUNT) c_prim++;
-        }
-    };
-    // wave-uniform lane masks.  sh* = context is on its shadow ray; pk* = a context that parks when its ray ends (diffuse or
-    // primary ray in flight, or no path while paths are left)
-    uint64_t mA = 0, mB = 0, shA = 0, shB = 0, pkA = ~0ull, pkB = ~0ull;
-    for (;;) {
-        uint64_t needA = ~mA & pkA, needB = ~mB & pkB;
-        {
-            // ---- step loop (falls through into the pass: no detour over the outer loop's header) --------------------
-            while ((uint32_t)__popcll(needA) < threshold && (uint32_t)__popcll(needB) < threshold && (mA | mB) != 0ull) {
-                // fetches of both contexts first (:106 for a fresh ray, :137 otherwise), so their latencies overlap
-                const uint32_t bA = LOGR == 8 ? A.r.vox >> 6 : A.r.cidx, bB = LOGR == 8 ? B.r.vox >> 6 : B.r.cidx;
-                const uint32_t wA = s_nib[bA >> 1], wB = s_nib[bB >> 1];
-                uint32_t stA = (wA >> ((bA & 1u) << 2)) & 15u, stB = (wB >> ((bB & 1u) << 2)) & 15u;
-                const bool gA = A.r.tracing && stA == kNibMixed, gB = B.r.tracing && stB == kNibMixed;
-                uint8_t byA = 0, byB = 0;
-                if (gA) byA = sc.mine[A.r.vox];
-                if (gB) byB = sc.mine[B.r.vox];
-                if (gA) stA = byA;
-                if (gB) stB = byB;
-                if (COUNT) {
-                    const uint32_t nA = (uint32_t)__popcll(mA), nB = (uint32_t)__popcll(mB);
-                    d_iters++; if (nA) { d_sx++; d_sl += nA; } if (nB) { d_fx++; d_fl += nB; }
-                }
-                if (A.r.tracing) advance(A.r, stA);
-                if (B.r.tracing) advance(B.r, stB);
-                mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
-                const uint64_t rA = shA & ~mA, rB = shB & ~mB;
-                const uint32_t nre = (uint32_t)__popcll(rA) + (uint32_t)__popcll(rB);
-                if (nre >= rmin || ((mA | mB) == 0ull && nre != 0u)) {
-                    rearm(A); rearm(B);
-                    mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
-                    shA &= ~rA; shB &= ~rB; pkA |= rA; pkB |= rB;
-                }
-                needA = ~mA & pkA; needB = ~mB & pkB;
-            }
-        }
-        if ((needA | needB) == 0ull) {
-            // no ray in flight and no context parked: only finished shadow rays can be left
-            const uint64_t rA = shA & ~mA, rB = shB & ~mB;
-            if ((rA | rB) == 0ull) break;             // ... or nothing at all: the wave is done
-            rearm(A); rearm(B);
-            mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
-            shA &= ~rA; shB &= ~rB; pkA |= rA; pkB |= rB;
-            continue;
-        }
-
-        // serve the context type with more parked lanes
-        if ((uint32_t)__popcll(needA) >= (uint32_t)__popcll(needB)) pass(A); else pass(B);
-        mA = __ballot(A.r.tracing); mB = __ballot(B.r.tracing);
-        shA = __ballot(c2_phase(A) == P2_SHADOW); shB = __ballot(c2_phase(B) == P2_SHADOW);
-        pkA = __ballot(c2_parks(A, exhausted)); pkB = __ballot(c2_parks(B, exhausted));
-    }
-    if (COUNT) {
-        DevCounters* cn = a.counters;
-        const unsigned long long rays = c_prim + c_shadow + c_dif;
-        wave_add(&cn->rays, rays); wave_add(&cn->rays_primary, c_prim); wave_add(&cn->rays_shadow, c_shadow);
-        wave_add(&cn->rays_diffuse, c_dif); wave_add(&cn->iterations, c_iter); wave_add(&cn->minefield_fetches, rays + c_iter);
-        wave_add(&cn->hits, c_hits); wave_add(&cn->material_fetches, c_hits); wave_add(&cn->sky_exits, c_sky);
-        wave_add(&cn->limit_exits, c_limit); wave_add(&cn->border_fetches, c_border); wave_add(&cn->noise_fetches, c_noise);
-        wave_add(&cn->pixels, c_pix);
-        if (lane == 0) {
-            atomicAdd(&cn->dbg_loop_iters, d_iters); atomicAdd(&cn->dbg_s_execs, d_sx); atomicAdd(&cn->dbg_f_execs, d_fx);
-            atomicAdd(&cn->dbg_s_lanes, d_sl); atomicAdd(&cn->dbg_f_lanes, d_fl); atomicAdd(&cn->dbg_passes, d_pass);
-            atomicAdd(&cn->dbg_pass_lanes, d_pl); atomicAdd(&cn->dbg_sky_lanes, d_sky);
-        }
-    }
-}
-
 // acc[pixel] (+)= the batch's samples of that pixel, in sample order (deterministic fp32 sum; raytrace.comp has one
 // sample per frame, the sum over frames is the build's spp extension).  The last batch of a frame writes the pixel's
 // lighting planes itself (sum / spp / 16, raytrace.comp:352-356) — the prepass has done that for the pixels it finished —
@@ -1027,8 +671,7 @@ static void launch_persist_logr(const Scene& sc, const Frame& f, const Planes& p
     const bool lrz = f.lr_zero != 0;
 #define RT_LAUNCH_PERSIST(L, C, K)                                                                        \
     do {                                                                                                  \
-        if (version == 2) hipLaunchKernelGGL((k_persist2<LOGR, L, C, K>), grid, block, 0, st, sc, f, pl, a); \
-        else hipLaunchKernelGGL((k_persist<LOGR, L, C, K>), grid, block, 0, st, sc, f, pl, a);            \
+        hipLaunchKernelGGL((k_persist<LOGR, L, C, K>), grid, block, 0, st, sc, f, pl, a);                \
     } while (0)
     if (lrz) {
         if (count) { if (cache) RT_LAUNCH_PERSIST(true, true, true); else RT_LAUNCH_PERSIST(true, true, false); }

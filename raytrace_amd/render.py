@@ -13,7 +13,7 @@ import math
 import numpy as np
 
 from . import _lib
-from .abi import (BUFFER_FORMATS, BUFFER_NAMES, RT_BUF_COUNT, RT_BUF_FINAL_BGRA8, RT_KERNEL_DEFAULT, RtConfig, RtCounters, RtTiming,
+from .abi import (BUFFER_FORMATS, BUFFER_NAMES, RT_BUF_COUNT, RT_BUF_FINAL_BGRA8, RT_KERNEL_DEFAULT, RtConfig, RtCounters, RtInfo, RtTiming,
                   RtUniforms)
 
 
@@ -230,6 +230,12 @@ class Context:
 
     def reset_counters(self):
         self._check(self._lib.rt_reset_counters(self._h))
+
+    def info(self):
+        i = RtInfo()
+        i.struct_size = C.sizeof(RtInfo)
+        self._check(self._lib.rt_get_info(self._h, C.byref(i)))
+        return i
 
     def timing(self):
         t = RtTiming()

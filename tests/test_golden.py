@@ -39,7 +39,7 @@ def test_oracle_reproduces_golden(case, scenes_cache, blue_noise):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2, abi.RT_KERNEL_WAVEFRONT, abi.RT_KERNEL_MEGA])
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_WAVEFRONT, abi.RT_KERNEL_MEGA])
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_gpu_reproduces_golden(case, kernel, scenes_cache, blue_noise):
     scene, W, H, spp, depth, origin, heading, pitch, sun, seed, lr = CASES[case]

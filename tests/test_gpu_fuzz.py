@@ -39,8 +39,6 @@ def test_random_cases_match_oracle(scene_name, procedural_region, blue_noise):
         cpu, ccn = po.render(mats, mine, blue_noise, u, case["W"], case["H"], case["spp"], case["depth"])
         for kernel, flags in ((abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS),
                               (abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_CACHE_PRIMARY),
-                              (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_COUNTERS),
-                              (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_CACHE_PRIMARY),
                               (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY),
                               (abi.RT_KERNEL_SEQ, abi.RT_FLAG_CACHE_PRIMARY),
                               (abi.RT_KERNEL_MEGA, abi.RT_FLAG_COUNTERS)):

@@ -15,7 +15,7 @@ from tests import scenes
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [abi.RT_KERNEL_MEGA, abi.RT_KERNEL_WAVEFRONT, abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2]
+KERNELS = [abi.RT_KERNEL_MEGA, abi.RT_KERNEL_WAVEFRONT, abi.RT_KERNEL_PERSISTENT]
 RMS_TOL = 1e-4  # BASELINE.json north_star: per-pixel RMS error <= 1e-4 vs the CPU reference
 
 
@@ -63,7 +63,7 @@ def _cached_counters(mats, mine, noise, u, W, H, spp, depth, ccn, **kw):
     return d
 
 
-PATH_KERNELS = [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PERSISTENT2, abi.RT_KERNEL_PATHS, abi.RT_KERNEL_SEQ]
+PATH_KERNELS = [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PATHS, abi.RT_KERNEL_SEQ]
 
 CASES = [
     # W, H, spp, depth
@@ -426,11 +426,21 @@ def test_bench_two_rank_rehearsal_assembles_the_same_frame():
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_SINGLE_DEVICE="1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", "bench.py", "--gpus", "2"] + common, cwd=ROOT, capture_output=True, text=True,
-                         timeout=600, env=env)
+                          "--master-port", "29533", "bench.py", "--gpus", "2"] + common[:-1], cwd=ROOT, capture_output=True, text=True,
+                         timeout=600, env=env)      # common[:-1]: the CPU baseline runs at N > 1 too (rank 0, after the timed region)
     assert two.returncode == 0, two.stderr[-3000:]
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
+    # the N > 1 line is as complete as the N = 1 line: CPU baseline, per-rank spread, and the C4 frame's own roofline
+    assert j2["cpu_baseline"] is not None and j2["cpu_baseline"]["value"] > 0 and j2["cpu_baseline"]["kind"] == "port"
+    spread = j2["roofline"]["ranks_path_kernel_ms_per_frame"]
+    assert 0 < spread["min"] <= spread["max"]
+    rays = j2["roofline"]["ranks_rays_per_frame"]
+    assert rays["min"] <= rays["max"] and rays["min"] + rays["max"] == j2["config"]["rays_per_frame"]    # two ranks
+    c4 = j2["c4"]
+    assert c4["workload"].startswith("3840x2160 spp=256 depth=8") and c4["value"] > 0
+    assert c4["roofline"]["frac"] > 0 and c4["roofline"]["kernel"] == "k_paths" and c4["roofline"]["avg_launch_ms"] > 0
+    assert j2["config"]["samples_per_launch"] >= 1 and j2["config"]["light_record_bytes"] <= j2["config"]["light_record_budget_bytes"]
     assert j1["config"]["frame_sha256_16"] == j2["config"]["frame_sha256_16"]
     assert j1["config"]["rays_per_frame"] == j2["config"]["rays_per_frame"]
     for j in (j1, j2):
@@ -471,8 +481,6 @@ def region512(native_built):
 
 @pytest.mark.parametrize("kernel,flags", [(abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS),
                                           (abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_CACHE_PRIMARY),
-                                          (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_COUNTERS),
-                                          (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_CACHE_PRIMARY),
                                           (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY),
                                           (abi.RT_KERNEL_MEGA, abi.RT_FLAG_COUNTERS)])
 @pytest.mark.parametrize("pose", [
@@ -507,14 +515,20 @@ def test_region_size_validation(native_built):
         render.Context(render.make_config(64, 64, region=512, kernel=abi.RT_KERNEL_WAVEFRONT))
 
 
-def test_region_1024_matches_oracle(blue_noise, native_built):
-    """Config C5's scene size: 1024^3 (1 GiB minefield + 4 GiB materials — larger than the 256 MiB Infinity Cache)."""
-    mats, mine = world.generate_region(world.DEFAULT_SEED, region=1024)
+@pytest.fixture(scope="module")
+def region1024(native_built):
+    """Config C5's scene: 1024^3 (1 GiB minefield + 4 GiB materials — larger than the 256 MiB Infinity Cache)."""
+    return world.generate_region(world.DEFAULT_SEED, region=1024)
+
+
+def test_region_1024_matches_oracle(blue_noise, region1024):
+    """Config C5's scene size at a small frame, on k_persist and k_paths, and through a scrolled window."""
+    mats, mine = region1024
     u = po.camera_uniforms((-120.0, -512.0, 400.0), np.pi / 2, -0.3, 0.0, 1)
     W, H, spp, depth = 96, 64, 2, 3
     cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth, region=1024)
-    for kernel, flags in ((abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS), (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_COUNTERS),
-                          (abi.RT_KERNEL_PERSISTENT2, abi.RT_FLAG_CACHE_PRIMARY), (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY),
+    for kernel, flags in ((abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS), (abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_CACHE_PRIMARY),
+                          (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY),
                           (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS)):
         cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=kernel, flags=flags, region=1024)
         with render.Context(cfg) as ctx:
@@ -544,6 +558,93 @@ def test_region_1024_matches_oracle(blue_noise, native_built):
         assert ctx.kernel_in_use() == abi.RT_KERNEL_PATHS
         gpu = ctx.readback_all()
     _compare(gpu, cpu)
+
+
+@pytest.mark.parametrize("region,depth", [(512, 8), (512, 9), (1024, 8), (1024, 9)])
+def test_deep_paths_on_the_larger_regions(blue_noise, region512, region1024, region, depth):
+    """Depth 8 and 9 at regions 512 and 1024 (VERDICT r2 #2b): k_paths<., STK = 1, LOGR = 9 / 10> — the albedo stack in global
+    memory next to the large swizzle tables, the instantiation the benchmarked C5 frame runs — and k_persist, planes and the
+    exact counters against the oracle."""
+    mats, mine = region512 if region == 512 else region1024
+    s = region // 256
+    u = po.camera_uniforms((-30.0 * s, -128.0 * s, 100.0 * s), np.pi / 2, -0.25, 0.4, 5)
+    W, H, spp = 40, 24, 2
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth, region=region)
+    cached = _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn, region=region)
+    for kernel, flags in ((abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY), (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS),
+                          (abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS)):
+        cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=kernel, flags=flags, region=region)
+        with render.Context(cfg) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(u)
+            ctx.sync()
+            assert ctx.kernel_in_use() == kernel
+            gpu, gcn = ctx.readback_all(), ctx.counters()
+        if flags == abi.RT_FLAG_COUNTERS:
+            _compare(gpu, cpu, gcn, ccn)
+        else:
+            _compare(gpu, cpu)
+            if flags & abi.RT_FLAG_COUNTERS:
+                assert gcn.as_dict() == cached
+
+
+C5 = (3840, 2160, 1024, 8)     # BASELINE.json config 5 on the 1024^3 region
+
+
+def test_c5_frame_properties_and_oracle_bands(blue_noise, region1024):
+    """The benchmarked C5 frame at its own size (VERDICT r2 #2a): 1024^3 region, 3840x2160 spp 1024 depth 8 through
+    RT_KERNEL_DEFAULT — six 172-sample launches of k_paths<false, 1, 10, true>, path indices beyond 2^30.  Determinism (drawn
+    twice), primary-plane identity with an spp-1 depth-0 frame, the counting build's identities (and equal planes), and two
+    8-row bands against the oracle."""
+    mats, mine = region1024
+    W, H, spp, depth = C5
+    u = po.camera_uniforms((-120.0, -512.0, 400.0), np.pi / 2, 0.0, 0.0, 1)     # bench.py --region 1024: the default pose scaled
+    cfg = render.make_config(W, H, spp=spp, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY, region=1024)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(u)
+        ctx.sync()
+        assert ctx.kernel_in_use() == abi.RT_KERNEL_PATHS
+        inf = ctx.info()
+        assert 1 <= inf.samples_per_launch <= spp and inf.light_record_bytes <= inf.light_record_budget_bytes
+        a1 = ctx.readback_all()
+        ctx.draw_frame(u)
+        ctx.sync()
+        a2 = ctx.readback_all()
+    for name in a1:
+        assert np.array_equal(a1[name], a2[name], equal_nan=True), name
+    del a2
+    cfg = render.make_config(W, H, spp=1, depth=0, region=1024)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(u)
+        ctx.sync()
+        p1 = ctx.readback_all()
+    for name in ("depth_r16", "normal_r8", "albedo_rgba8", "emission_rgba8", "fog_rgba8", "depth_f32", "fog_f32"):
+        assert np.array_equal(a1[name], p1[name], equal_nan=True), name
+    del p1
+    cfg = render.make_config(W, H, spp=spp, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS, region=1024)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        ctx.draw_frame(u)
+        ctx.sync()
+        b1, cn = ctx.readback_all(), ctx.counters()
+    for name in a1:
+        assert np.array_equal(a1[name], b1[name], equal_nan=True), name
+    del b1
+    assert cn.frames == 1 and cn.pixels == W * H and cn.rays_primary == W * H
+    assert cn.minefield_fetches == cn.rays + cn.iterations
+    assert cn.rays_shadow == cn.rays_diffuse and cn.noise_fetches == cn.rays_shadow + spp
+    assert cn.hits + cn.sky_exits + cn.limit_exits == cn.rays and cn.material_fetches == cn.hits
+    assert cn.rays_shadow > (1 << 30)       # more first-level paths than 2^30: the 32-bit path indices of a 172-sample launch are in use
+    for rows in ((536, 544), (1336, 1344)):
+        cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth, rows=rows, region=1024)
+        for name in cpu:
+            assert np.array_equal(a1[name][rows[0]:rows[1]], cpu[name][rows[0]:rows[1]], equal_nan=True), (name, rows)
 
 
 @pytest.mark.parametrize("kernel", PATH_KERNELS)

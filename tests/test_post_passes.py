@@ -121,6 +121,33 @@ def test_gpu_post_passes_match_oracle(procedural_region, blue_noise, W, H, spp, 
 
 
 @pytest.mark.gpu
+def test_gpu_post_passes_match_oracle_at_1080p(procedural_region, blue_noise):
+    """The post passes at the benchmark's frame size (VERDICT r2 #2c): six denoise dispatches (LDS-tiled sizes 1 and 2, direct
+    4, 8, 8, 16) and finalize at 1920x1080 against the oracle, with the reference's pong binding and with the consistent one."""
+    mats, mine = procedural_region
+    W, H = 1920, 1080
+    u = po.camera_uniforms((-30.0, -128.0, 100.0), np.pi / 2, -0.1, 0.3, 5)
+    cfg = render.make_config(W, H, spp=4, depth=2, flags=abi.RT_FLAG_CACHE_PRIMARY)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        for faithful in (True, False):
+            ctx.draw_frame(u)
+            ctx.sync()
+            g = ctx.readback_all()
+            ctx.denoise(faithful=faithful)
+            ctx.sync()
+            den = ctx.readback(abi.RT_BUF_LIGHTING_RGBA16)
+            ctx.finalize()
+            ctx.sync()
+            fin = ctx.readback(abi.RT_BUF_FINAL_BGRA8)
+            exp_den = po.denoise(g["lighting_rgba16"], g["depth_r16"], g["normal_r8"], faithful=faithful)
+            assert np.array_equal(den, exp_den), "denoise (faithful=%s) differs at %d values" % (faithful, int(np.count_nonzero(den != exp_den)))
+            exp_fin = po.finalize(g["albedo_rgba8"], g["emission_rgba8"], g["fog_rgba8"], exp_den, g["depth_r16"], blue_noise)
+            assert np.array_equal(fin, exp_fin), "finalize (faithful=%s) differs at %d bytes" % (faithful, int(np.count_nonzero(fin != exp_fin)))
+
+
+@pytest.mark.gpu
 def test_denoise_division_is_exact_on_its_whole_domain(native_built):
     """The denoise passes replace the IEEE division of bilateral_denoise.comp:31 by a reciprocal and one residual correction;
     rt_selftest compares the two over EVERY value the expression can take (37 weights x {k/64 + 1, k/64 + 11 : k < 65536}) on

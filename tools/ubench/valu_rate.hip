@@ -102,6 +102,7 @@ void run(const char* name, float* out, unsigned long long* cyc) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);   // every result reaches the file even if a later kind dies
     float* out; unsigned long long* cyc;
     (void)hipMalloc(&out, 256 * 1024 * sizeof(float));
     (void)hipMalloc(&cyc, 256 * 16 * sizeof(unsigned long long));
