@@ -110,7 +110,7 @@ typedef enum RtKernel {
 #define RT_FLAG_TIMING        0x4u  /* bracket the traversal-kernel launches with HIP events (RtTiming.trace_ms)  */
 #define RT_FLAG_TIMING_ALL    0xCu  /* ... and every other launch as well (RtTiming.shade_ms); includes RT_FLAG_TIMING */
 #define RT_FLAG_TRUSTED_WORLD 0x10u /* rt_upload_slice: the host vouches that every minefield value is <= 30 (the reference
-                                       writes 0..6); the slab is applied without the device->host round trip of the check */
+                                       writes 0..6); the slab is applied without the host-side scan of its bytes        */
 
 /*
  * RtConfig — replaces the compile-time window constants (constants.rs:9-10) and adds the
@@ -222,9 +222,9 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
  * launch over its 16 R^2 voxels + the nibble-map words it touches); any region size.
  * Asynchronous: the slab is copied into pinned staging (the host's buffers are free again at return), transferred on the
  * library's upload stream and applied on the context's stream after the frames already submitted — the call does not wait
- * for them (the reference does: vkQueueWaitIdle, pipeline.rs:181-189).  Without RT_FLAG_TRUSTED_WORLD the staged minefield
- * is checked first (values above 30 -> RT_ERR_INVALID_ARG); a rejected slab is NOT applied: the region and what can be
- * drawn stay as they were. */
+ * for them (the reference does: vkQueueWaitIdle, pipeline.rs:181-189).  Without RT_FLAG_TRUSTED_WORLD the minefield
+ * is checked first, on the host (values above 30 -> RT_ERR_INVALID_ARG); a rejected slab is NOT applied: the region and
+ * what can be drawn stay as they were. */
 int rt_upload_slice(RtContext* ctx, int axis, int texel_offset,
                     const uint32_t* materials, const uint8_t* minefield);
 

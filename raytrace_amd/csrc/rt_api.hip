@@ -47,8 +47,8 @@ struct RtContext {
     uint8_t* d_mine_sw = nullptr; uint32_t* d_mat_sw = nullptr;
     uint32_t* d_coarse = nullptr; uint32_t* d_noise = nullptr; uint32_t* d_flag = nullptr;
     // rt_upload_slice: one 16-thick slab travels pinned host staging -> device staging (own stream) -> re-tile (render stream)
-    uint8_t* d_slab_mine = nullptr; uint32_t* d_slab_mat = nullptr; uint32_t* d_slab_flag = nullptr;
-    uint8_t* h_slab_mine = nullptr; uint32_t* h_slab_mat = nullptr; uint32_t* h_slab_flag = nullptr;   // hipHostMalloc
+    uint8_t* d_slab_mine = nullptr; uint32_t* d_slab_mat = nullptr;
+    uint8_t* h_slab_mine = nullptr; uint32_t* h_slab_mat = nullptr;   // hipHostMalloc
     hipStream_t upload_stream = nullptr;
     hipEvent_t ev_slab_copied = nullptr, ev_slab_applied = nullptr;   // host staging read / device staging consumed
     bool slab_copy_pending = false, slab_apply_recorded = false;
@@ -474,7 +474,6 @@ void rt_destroy(RtContext* ctx) {
     if (ctx->ev_slab_applied) (void)hipEventDestroy(ctx->ev_slab_applied);
     if (ctx->h_slab_mat) (void)hipHostFree(ctx->h_slab_mat);
     if (ctx->h_slab_mine) (void)hipHostFree(ctx->h_slab_mine);
-    if (ctx->h_slab_flag) (void)hipHostFree(ctx->h_slab_flag);
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ev_frame0) (void)hipEventDestroy(ctx->ev_frame0);
@@ -529,10 +528,8 @@ int slab_resources(RtContext* ctx) {
     const size_t n = (size_t)RT_SLICE_SIZE * (size_t)ctx->region * (size_t)ctx->region;
     if (!ctx->d_slab_mat) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mat, n));
     if (!ctx->d_slab_mine) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mine, n));
-    if (!ctx->d_slab_flag) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_flag, 1));
     if (!ctx->h_slab_mat) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_mat, n * sizeof(uint32_t), hipHostMallocDefault));
     if (!ctx->h_slab_mine) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_mine, n, hipHostMallocDefault));
-    if (!ctx->h_slab_flag) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_flag, sizeof(uint32_t), hipHostMallocDefault));
     if (!ctx->upload_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
     if (!ctx->ev_slab_copied) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_copied, hipEventDisableTiming));
     if (!ctx->ev_slab_applied) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_applied, hipEventDisableTiming));
@@ -564,32 +561,26 @@ int rt_upload_slice(RtContext* ctx, int axis, int texel_offset, const uint32_t* 
     // Incremental and asynchronous.  The slab goes pinned host staging -> device staging (5 bytes x 16 x R^2) on the upload
     // stream; the render stream waits for that event (not the host), then ONE launch re-tiles the slab's 16 R^2 voxels into the
     // brick-swizzled arrays and a second rebuilds the nibble-map words it touches.  Frames in flight keep reading the region
-    // until then by stream order — no hipStreamSynchronize on the render stream (the reference blocks on vkQueueWaitIdle here,
-    // pipeline.rs:181-189).
+    // until then by stream order — the host waits for nothing on the device (the reference blocks on vkQueueWaitIdle here,
+    // pipeline.rs:181-189); only a previous slab still leaving the pinned staging is waited for.
     const size_t n = (size_t)RT_SLICE_SIZE * kR * kR;
     if (ctx->slab_copy_pending) { RT_HIP(ctx, hipEventSynchronize(ctx->ev_slab_copied)); ctx->slab_copy_pending = false; }
+    if ((ctx->cfg.flags & RT_FLAG_TRUSTED_WORLD) == 0) {
+        // values above 30 are rejected as in rt_upload_world — BEFORE anything is written or transferred: a rejected slab leaves
+        // the region (and what can be drawn) as it was.  The bytes are in host memory, so the check is a host loop over 16 R^2
+        // bytes (~20 us at R = 256) and needs no device round trip; a host that vouches for its data skips it.
+        uint8_t worst = 0;
+        for (size_t i = 0; i < n; i++) worst = minefield[i] > worst ? minefield[i] : worst;
+        if (worst > rtd::kMaxStepValue)
+            return fail(ctx, RT_ERR_INVALID_ARG, "minefield slab holds a value above 30 (the reference writes 0..6, src/world/chunk.rs:163-183); the region is unchanged");
+    }
     if (materials != ctx->h_slab_mat) memcpy(ctx->h_slab_mat, materials, n * sizeof(uint32_t));   // borrowed buffers are released at return;
     if (minefield != ctx->h_slab_mine) memcpy(ctx->h_slab_mine, minefield, n);                     // rt_slice_staging's pointers need no copy
     if (ctx->slab_apply_recorded) RT_HIP(ctx, hipStreamWaitEvent(ctx->upload_stream, ctx->ev_slab_applied, 0));   // the previous slab's re-tile has read the device staging
     RT_HIP(ctx, hipMemcpyAsync(ctx->d_slab_mine, ctx->h_slab_mine, n, hipMemcpyHostToDevice, ctx->upload_stream));
-    const bool validate = (ctx->cfg.flags & RT_FLAG_TRUSTED_WORLD) == 0;
-    if (validate) {
-        // values above 30 are rejected as in rt_upload_world — BEFORE anything is written: a rejected slab leaves the region
-        // (and what can be drawn) as it was.  The check reads the staged bytes on the upload stream, so its round trip does
-        // not wait for frames in flight; a host that vouches for its data (RT_FLAG_TRUSTED_WORLD) skips it.
-        RT_HIP(ctx, hipMemsetAsync(ctx->d_slab_flag, 0, sizeof(uint32_t), ctx->upload_stream));
-        RT_HIP(ctx, rtd::launch_check_slab(ctx->d_slab_mine, n, ctx->d_slab_flag, ctx->upload_stream));
-        RT_HIP(ctx, hipMemcpyAsync(ctx->h_slab_flag, ctx->d_slab_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->upload_stream));
-    }
     RT_HIP(ctx, hipMemcpyAsync(ctx->d_slab_mat, ctx->h_slab_mat, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->upload_stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_slab_copied, ctx->upload_stream));
     ctx->slab_copy_pending = true;
-    if (validate) {
-        RT_HIP(ctx, hipEventSynchronize(ctx->ev_slab_copied));
-        ctx->slab_copy_pending = false;
-        if (*ctx->h_slab_flag)
-            return fail(ctx, RT_ERR_INVALID_ARG, "minefield slab holds a value above 30 (the reference writes 0..6, src/world/chunk.rs:163-183); the region is unchanged");
-    }
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slab_copied, 0));
     {
         LaunchTimer t(ctx, 1);

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_flatten_voxels(const uint8_t* __restric
 // rt_upload_slice: the same re-tiling for ONE 16-thick slab (TerrainUploadManager::upload_slice, terrain_upload.rs:84-275 ->
 // vkCmdCopyBufferToImage with an offset).  The slab arrives as a dense box of extent 16 along `axis` and R along the other
 // two (x fastest); thread i handles swizzled voxel i of the slab's bricks — 4 brick layers along `axis`, whole bricks, so every
-// thread writes inside one 64-byte line run.  (The slab's values were checked before it got here: k_check_slab.)
+// thread writes inside one 64-byte line run.  (The slab's values were checked on the host before it got here: rt_upload_slice.)
 __global__ __launch_bounds__(256) void k_flatten_slab(const uint8_t* __restrict__ mine_slab, const uint32_t* __restrict__ mat_slab,
                                                       uint8_t* __restrict__ mine_sw, uint32_t* __restrict__ mat_sw,
                                                       int logr, int axis, int offset) {
@@ -66,19 +66,6 @@ __global__ __launch_bounds__(256) void k_flatten_slab(const uint8_t* __restrict_
     const size_t dst = ((((size_t)bc[2] << lb) + bc[1]) << lb) + bc[0];
     mine_sw[(dst << 6) | l] = mine_slab[src];
     mat_sw[(dst << 6) | l] = mat_slab[src];
-}
-
-// rt_upload_slice, before anything is written: does the staged slab hold a minefield value above kMaxStepValue (the reference
-// writes 0..6, chunk.rs:163-183)?  16 bytes per thread; n is a multiple of 4096.
-__global__ __launch_bounds__(256) void k_check_slab(const uint4* __restrict__ mine_slab, uint32_t nvec, uint32_t* __restrict__ bad_value_flag) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nvec) return;
-    const uint4 v = mine_slab[i];
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    bool bad = false;
-    for (int k = 0; k < 4; k++)
-        for (int b = 0; b < 4; b++) bad = bad || ((w[k] >> (8 * b)) & 0xFFu) > kMaxStepValue;
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(bad_value_flag, 1u);
 }
 
 // One thread per nibble-map word = 8 consecutive coarse cubes (x-adjacent).  A coarse cube has edge R/64 and is made of
@@ -537,12 +524,6 @@ hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint
                        bad_flag, logr);
     hipLaunchKernelGGL(k_build_coarse, dim3(kCoarseWords / 256), dim3(256), 0, st, mine_sw, coarse, logr, make_uint3(0, 0, 0),
                        make_uint3(8, 64, 64));
-    return hipGetLastError();
-}
-
-hipError_t launch_check_slab(const uint8_t* mine_slab, size_t nbytes, uint32_t* bad_flag, hipStream_t st) {
-    const uint32_t nvec = (uint32_t)(nbytes / 16u);
-    hipLaunchKernelGGL(k_check_slab, dim3((nvec + 255u) / 256u), dim3(256), 0, st, reinterpret_cast<const uint4*>(mine_slab), nvec, bad_flag);
     return hipGetLastError();
 }
 

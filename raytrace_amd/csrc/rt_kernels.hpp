@@ -99,7 +99,6 @@ hipError_t launch_seq(const Scene& sc, const Frame& f, const Planes& pl, const P
 
 hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
                           uint32_t* coarse, uint32_t* bad_flag, int logr, hipStream_t st);
-hipError_t launch_check_slab(const uint8_t* mine_slab, size_t nbytes, uint32_t* bad_flag, hipStream_t st);
 hipError_t launch_flatten_slab(const uint8_t* mine_slab, const uint32_t* mat_slab, uint8_t* mine_sw, uint32_t* mat_sw, uint32_t* coarse,
                                int logr, int axis, int offset, hipStream_t st);
 hipError_t launch_mega(const Scene& sc, const Frame& f, const Planes& pl, DevCounters* cn, bool count, hipStream_t st);

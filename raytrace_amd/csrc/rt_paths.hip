@@ -38,6 +38,8 @@
 // their tables leave no LDS for the albedo stack, which then lives in global memory (STK = 1).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
 #include "rt_pslot.hpp"
@@ -105,10 +107,15 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     const unsigned long long t_wave0 = wall_clock64();
     unsigned long long t_exh = 0;
 #endif
-    PSlot SA, FA, SB, FB;
+    // the four rays of the lane (shadow / diffuse of context A and B) and their per-lane booleans (rt_pslot.hpp: wave masks in SGPRs)
+    PRay SA, FA, SB, FB;
     SA.px = SA.py = SA.pz = SA.ndx = SA.ndy = SA.lx = SA.ly = SA.lz = 0.0f; SA.ndz = -1.0f;
-    SA.sx = SA.sy = SA.sz = 0u; SA.nk = K_DEAD | K_END; SA.axis = 2u;
+    SA.sx = SA.sy = SA.sz = 0u; SA.nk = (uint32_t)RT_TRACE_LIMIT;
     FA = SA; SB = SA; FB = SA;
+    lanemask rSA = 0, rFA = 0, rSB = 0, rFB = 0;                 // in flight
+    lanemask zFA = ~0ull, xyFA = 0, zFB = ~0ull, xyFB = 0;       // the diffuse ray's last step: along z / tx < ty (z: a ray that ends before its first step reports the z face, :90)
+    lanemask nul = 0, nul2 = 0;                                  // the shadow rays' unused axis masks
+    uint32_t looks = 0;
     PPath PA, PB;
     PA.st = PP_FINAL; PA.item = 0u; PA.ent = 7u << 16;
     PB = PA;
@@ -124,9 +131,8 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     unsigned long long c_shadow = 0, c_dif = 0, c_iter = 0, c_hits = 0, c_sky = 0, c_limit = 0, c_border = 0, c_noise = 0;
     unsigned long long d_iters = 0, d_passf = 0, d_plf = 0, d_live = 0;   // wave-uniform structure statistics (counting builds)
 
-    // minefield value of a slot's current texel (nibble map, byte array behind it), outside the step loop
-    auto lookup = [&](const PSlot& r) -> uint32_t {
-        const uint32_t vox = ps_vox(r);
+    // minefield value of a texel (nibble map, byte array behind it), outside the step loop
+    auto lookup = [&](uint32_t vox) -> uint32_t {
         if (!LRZ && ps_border(vox)) return 0u;
         uint32_t nb, nsh;
         ps_nibble_of<LOGR, LRZ>(vox, &nb, &nsh);
@@ -134,38 +140,38 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         if (st == kNibMixed) st = sc.mine[vox];
         return st;
     };
-    // How an ENDED ray that did not reach the sky stopped: 0 = hit (:146-160), 1 = loop limit (Q8: a non-air hit with
-    // material 0), 2 = special (Q12: fresh ray on a 0, NaN direction, first texel outside the texture: NaN position, material 0).
-    // The limit case needs the value of the ray's texel once more (nk == K_END: no iterations left) — practically never taken.
-    auto stop_kind = [&](const PSlot& r) -> uint32_t {
-        const uint32_t left = r.nk & 0xFFFFu;
-        uint32_t kind = ((r.nk & K_DEAD) != 0u || left == (uint32_t)RT_TRACE_LIMIT) ? 2u : 0u;
-        const bool at_limit = kind == 0u && left == 0u;
+    // How an ended ray that did not reach the sky stopped: 0 = hit (:146-160), 1 = loop limit (Q8: a non-air hit with
+    // material 0), 2 = special (Q12: it never moved — fresh ray on a 0, NaN direction, first texel outside the texture: NaN
+    // position, material 0).  The limit case needs the value of the ray's texel once more — practically never taken.
+    auto stop_kind = [&](uint32_t nk, uint32_t vox, bool consider) -> uint32_t {
+        const uint32_t left = nk & 0xFFFFu;
+        uint32_t kind = left == (uint32_t)RT_TRACE_LIMIT ? 2u : 0u;
+        const bool at_limit = consider && left == 0u;
         if (__builtin_expect(__ballot(at_limit) != 0ull, 0)) {
-            if (at_limit && lookup(r) != 0u) kind = 1u;
+            if (at_limit && lookup(vox) != 0u) kind = 1u;
         }
         return kind;
     };
-    auto tally = [&](const PSlot& r) {   // exact counters of one finished ray
+    auto tally = [&](const PRay& r) {   // exact counters of one finished ray (counting builds)
         const uint32_t left = r.nk & 0xFFFFu;
-        if (r.nk & K_AIR) {
+        if (pr_outside<LOGR, LRZ>(r.px, r.py, r.pz, f.lr[0], f.lr[1], f.lr[2])) {
             c_iter += (uint32_t)RT_TRACE_LIMIT - left;
             c_sky++;
             int tx, ty, tz;   // the fetch the shader makes before its sky test may hit the border
             if (!wrap_texel(v3(r.px, r.py, r.pz), (float)R, &tx, &ty, &tz)) c_border++;
         } else {
-            const uint32_t kind = stop_kind(r);
+            const uint32_t kind = stop_kind(r.nk, pr_vox(r), true);
             c_iter += kind == 2u ? 1u : (uint32_t)RT_TRACE_LIMIT - left;   // a ray that is special ends inside its first iteration
             if (kind == 1u) c_limit++; else c_hits++;
             if (kind == 2u) c_border += 1u + ((r.nk & kFreshInvalid) ? 1u : 0u);
-            else if (!LRZ && ps_border(ps_vox(r))) c_border++;   // the fetch that ended it went to the border texel
+            else if (!LRZ && ps_border(pr_vox(r))) c_border++;   // the fetch that ended it went to the border texel
         }
     };
-    // the first step of a fresh ray whose origin lies outside the region (rare; GENERIC_Q in p_advance)
+    // the first step of a fresh ray whose origin lies outside the region (rare; the generic q of p_advance, flag-word bookkeeping)
     auto first_step = [&](PSlot& r, bool en) {
         en = en && ps_running(r.nk);
         uint32_t st = 0;
-        if (en) st = lookup(r);
+        if (en) st = lookup(ps_vox(r));
         p_advance<true, 1, LOGR, LRZ>(r, st, en, swz, f.lr[0], f.lr[1], f.lr[2]);
     };
 
@@ -196,20 +202,26 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     // dependent round trips.)  A lane that has nothing to fetch reads element 0.
     constexpr uint32_t PP_SNAN = 1u << 19, PP_FNAN = 1u << 18;   // PPath::st: the shadow / diffuse direction in the slot registers has a NaN
     auto pass = [&]() {
-        const bool endA = min(SA.nk, FA.nk) >= K_END, endB = min(SB.nk, FB.nk) >= K_END;
+        const bool endA = !lm_lane(rSA | rFA), endB = !lm_lane(rSB | rFB);
         const bool workA = endA && !(exhausted && (PA.st >> 20) == 0u), workB = endB && !(exhausted && (PB.st >> 20) == 0u);
         const bool act = workA || workB, useB = !workA && workB;
         const uint32_t c = useB ? 1u : 0u;
         // the lane's context
-        const uint32_t Snk = useB ? SB.nk : SA.nk, Fnk = useB ? FB.nk : FA.nk, Faxis = useB ? FB.axis : FA.axis;
+        const uint32_t Fnk = useB ? FB.nk : FA.nk;
         const float Fpx = useB ? FB.px : FA.px, Fpy = useB ? FB.py : FA.py, Fpz = useB ? FB.pz : FA.pz;
         const float Fdx = useB ? FB.ndx : FA.ndx, Fdy = useB ? FB.ndy : FA.ndy, Fdz = useB ? FB.ndz : FA.ndz;
-        const uint32_t Fvox = useB ? ps_vox(FB) : ps_vox(FA);
+        const uint32_t Fvox = useB ? pr_vox(FB) : pr_vox(FA);
+        const lanemask useBm = __ballot(useB);
+        const uint32_t Faxis = lm_lane((zFB & useBm) | (zFA & ~useBm)) ? 2u : (lm_lane((xyFB & useBm) | (xyFA & ~useBm)) ? 0u : 1u);
+        // whether an ended ray reached the sky is read off its position (:138-145)
+        const bool Sair = useB ? pr_outside<LOGR, LRZ>(SB.px, SB.py, SB.pz, f.lr[0], f.lr[1], f.lr[2])
+                               : pr_outside<LOGR, LRZ>(SA.px, SA.py, SA.pz, f.lr[0], f.lr[1], f.lr[2]);
+        const bool Fair = pr_outside<LOGR, LRZ>(Fpx, Fpy, Fpz, f.lr[0], f.lr[1], f.lr[2]);
         uint32_t Pst = useB ? PB.st : PA.st, Pitem = useB ? PB.item : PA.item, Pent = useB ? PB.ent : PA.ent;
 
         const uint32_t level = Pst >> 20;
         const bool mine = act && level != 0u;
-        const bool fin = mine && ((Fnk | Pst) & K_AIR) != 0u;   // sky exit or last level: the path ends
+        const bool fin = mine && (Fair || (Pst & PP_FINAL) != 0u);   // sky exit or last level: the path ends
         const bool cont = mine && !fin;
         if (COUNT) {
             d_passf++; d_plf += (uint32_t)__popcll(__ballot(mine));
@@ -258,17 +270,8 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         }
 
         // ---- first batch of loads
-        const bool air = fin && (Fnk & K_AIR) != 0u;
-        // How an ENDED ray that did not reach the sky stopped: 0 = hit (:146-160), 1 = loop limit (Q8: a non-air hit with
-        // material 0), 2 = special (Q12: fresh ray on a 0, NaN direction, first texel outside the texture: NaN position,
-        // material 0).  The limit case needs the value of the ray's texel once more — practically never taken.
-        uint32_t kind = ((Fnk & K_DEAD) != 0u || (Fnk & 0xFFFFu) == (uint32_t)RT_TRACE_LIMIT) ? 2u : 0u;
-        {
-            const bool at_limit = cont && kind == 0u && (Fnk & 0xFFFFu) == 0u;
-            if (__builtin_expect(__ballot(at_limit) != 0ull, 0)) {
-                if (at_limit && (useB ? lookup(FB) : lookup(FA)) != 0u) kind = 1u;
-            }
-        }
+        const bool air = fin && Fair;
+        const uint32_t kind = stop_kind(Fnk, Fvox, cont);   // 0 = hit, 1 = loop limit, 2 = special
         const bool hit = cont && kind == 0u;
         const float4 skyv = a.dif_lut[air ? 4u * Pent + 3u : 0u];   // :331-332 / :343-345, tabulated per frame; Pent = the entry F walked
         const uint32_t matv = sc.mat[(hit && !(!LRZ && ps_border(Fvox))) ? Fvox : 0u];   // the hit texel is the texel of the last fetch (:150-154); border: 0
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
 
         // ---- a path ends: L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
         uint32_t sunbits = Pst & 0xFFFFu;
-        if (mine && (Snk & K_AIR)) sunbits |= 1u << (level - 1u);               // :326-328 / :338-340
+        if (mine && Sair) sunbits |= 1u << (level - 1u);                          // :326-328 / :338-340
         if (fin) {
             vec3 L = v3(0.0f, 0.0f, 0.0f);
             if (sunbits >> (level - 1u) & 1u) L = vadd(L, sunlight);
@@ -364,35 +367,50 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             Pst = (Pst & ~PP_FNAN) | ((d2.x != d2.x || d2.y != d2.y || d2.z != d2.z) ? PP_FNAN : 0u);
         }
         if (getnew) Pst |= (sd.x != sd.x || sd.y != sd.y || sd.z != sd.z) ? PP_SNAN : 0u;
-        // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
-        const uint32_t dead = K_DEAD | K_END | ((COUNT && !ok) ? kFreshInvalid : 0u);
-        const uint32_t nkS = ((Pst & PP_SNAN) || !ok) ? dead : (uint32_t)RT_TRACE_LIMIT;
-        const uint32_t nkF = ((Pst & PP_FNAN) || !ok) ? dead : (uint32_t)RT_TRACE_LIMIT;
+        // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray never runs
+        bool runS = start && !((Pst & PP_SNAN) || !ok), runF = start && !((Pst & PP_FNAN) || !ok);
+        const uint32_t nk0 = (uint32_t)RT_TRACE_LIMIT | ((COUNT && !ok) ? kFreshInvalid : 0u);
         // (lr = 0 builds step with the q of in-region positions; a level whose origin lies outside takes its first step apart)
         const bool outside = LRZ && start && ok && (sfx + half < 0.0f || sfy + half < 0.0f || sfz + half < 0.0f);
 
         // the two fresh rays as they enter the step loop
-        PSlot TS, TF;
-        TS.px = sfx; TS.py = sfy; TS.pz = sfz; TS.sx = tx; TS.sy = ty; TS.sz = tz; TS.nk = nkS; TS.axis = 2u;
-        TF = TS; TF.nk = nkF;     // axis 2: a ray that ends before its first step reports the z face (:90)
+        float Spx = sfx, Spy = sfy, Spz = sfz, Tpx = sfx, Tpy = sfy, Tpz = sfz;
+        uint32_t Ssx = tx, Ssy = ty, Ssz = tz, Tsx = tx, Tsy = ty, Tsz = tz, nkS = nk0, nkF = nk0;
+        bool Tz = true, Txy = false;     // a ray that ends before its first step reports the z face (:90)
         if (__builtin_expect(__ballot(outside) != 0ull, 0)) {   // rare: the level's origin lies outside the region
+            PSlot TS, TF;
+            TS.px = sfx; TS.py = sfy; TS.pz = sfz; TS.sx = tx; TS.sy = ty; TS.sz = tz; TS.axis = 2u;
+            TS.nk = runS ? (uint32_t)RT_TRACE_LIMIT : (K_DEAD | K_END);
+            TF = TS; TF.nk = runF ? (uint32_t)RT_TRACE_LIMIT : (K_DEAD | K_END);
             TS.ndx = getnew ? -sd.x : (useB ? SB.ndx : SA.ndx); TS.ndy = getnew ? -sd.y : (useB ? SB.ndy : SA.ndy);
             TS.ndz = getnew ? -sd.z : (useB ? SB.ndz : SA.ndz);
             TS.lx = getnew ? sl.x : (useB ? SB.lx : SA.lx); TS.ly = getnew ? sl.y : (useB ? SB.ly : SA.ly); TS.lz = getnew ? sl.z : (useB ? SB.lz : SA.lz);
             TF.ndx = newface ? -d2.x : Fdx; TF.ndy = newface ? -d2.y : Fdy; TF.ndz = newface ? -d2.z : Fdz;
             TF.lx = newface ? dl.x : (useB ? FB.lx : FA.lx); TF.ly = newface ? dl.y : (useB ? FB.ly : FA.ly); TF.lz = newface ? dl.z : (useB ? FB.lz : FA.lz);
             first_step(TS, outside); first_step(TF, outside);
+            if (outside) {   // back from the flag word to the booleans
+                Spx = TS.px; Spy = TS.py; Spz = TS.pz; Ssx = TS.sx; Ssy = TS.sy; Ssz = TS.sz;
+                Tpx = TF.px; Tpy = TF.py; Tpz = TF.pz; Tsx = TF.sx; Tsy = TF.sy; Tsz = TF.sz;
+                if (runS) { runS = ps_running(TS.nk); nkS = TS.nk & 0xFFFFu; }
+                if (runF) { runF = ps_running(TF.nk); nkF = TF.nk & 0xFFFFu; Tz = TF.axis == 2u; Txy = TF.axis == 0u; }
+            }
         }
 
         // ---- write the lane's context back
         if (useB) { PB.st = Pst; PB.item = Pitem; PB.ent = Pent; } else { PA.st = Pst; PA.item = Pitem; PA.ent = Pent; }
-        if (start && !useB) {
-            SA.px = TS.px; SA.py = TS.py; SA.pz = TS.pz; SA.sx = TS.sx; SA.sy = TS.sy; SA.sz = TS.sz; SA.nk = TS.nk;
-            FA.px = TF.px; FA.py = TF.py; FA.pz = TF.pz; FA.sx = TF.sx; FA.sy = TF.sy; FA.sz = TF.sz; FA.nk = TF.nk; FA.axis = TF.axis;
+        const bool startA = start && !useB, startB = start && useB;
+        if (startA) {
+            SA.px = Spx; SA.py = Spy; SA.pz = Spz; SA.sx = Ssx; SA.sy = Ssy; SA.sz = Ssz; SA.nk = nkS;
+            FA.px = Tpx; FA.py = Tpy; FA.pz = Tpz; FA.sx = Tsx; FA.sy = Tsy; FA.sz = Tsz; FA.nk = nkF;
         }
-        if (start && useB) {
-            SB.px = TS.px; SB.py = TS.py; SB.pz = TS.pz; SB.sx = TS.sx; SB.sy = TS.sy; SB.sz = TS.sz; SB.nk = TS.nk;
-            FB.px = TF.px; FB.py = TF.py; FB.pz = TF.pz; FB.sx = TF.sx; FB.sy = TF.sy; FB.sz = TF.sz; FB.nk = TF.nk; FB.axis = TF.axis;
+        if (startB) {
+            SB.px = Spx; SB.py = Spy; SB.pz = Spz; SB.sx = Ssx; SB.sy = Ssy; SB.sz = Ssz; SB.nk = nkS;
+            FB.px = Tpx; FB.py = Tpy; FB.pz = Tpz; FB.sx = Tsx; FB.sy = Tsy; FB.sz = Tsz; FB.nk = nkF;
+        }
+        {
+            const lanemask sA = __ballot(startA), sB = __ballot(startB), mS = __ballot(runS), mF = __ballot(runF), mz = __ballot(Tz), mxy = __ballot(Txy);
+            rSA = (rSA & ~sA) | (mS & sA); rFA = (rFA & ~sA) | (mF & sA); zFA = (zFA & ~sA) | (mz & sA); xyFA = (xyFA & ~sA) | (mxy & sA);
+            rSB = (rSB & ~sB) | (mS & sB); rFB = (rFB & ~sB) | (mF & sB); zFB = (zFB & ~sB) | (mz & sB); xyFB = (xyFB & ~sB) | (mxy & sB);
         }
         if (newface && !useB) { FA.ndx = -d2.x; FA.ndy = -d2.y; FA.ndz = -d2.z; FA.lx = dl.x; FA.ly = dl.y; FA.lz = dl.z; }
         if (newface && useB) { FB.ndx = -d2.x; FB.ndy = -d2.y; FB.ndz = -d2.z; FB.lx = dl.x; FB.ly = dl.y; FB.lz = dl.z; }
@@ -400,11 +418,77 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         if (getnew && useB) { SB.ndx = -sd.x; SB.ndy = -sd.y; SB.ndz = -sd.z; SB.lx = sl.x; SB.ly = sl.y; SB.lz = sl.z; }
     };
 
+    // ---- one step of all four rays: nibble reads, then byte loads, then the arithmetic ----
+    // SHADOW: the shadow rays step too.  CAREFUL: the steps test the iteration counter (p_step).
+    auto step_all = [&](auto shadow_tag, auto careful_tag) {
+        constexpr bool SHADOW = decltype(shadow_tag)::value, CAREFUL = decltype(careful_tag)::value;
+        const uint32_t v1 = pr_vox(FA), v3_ = pr_vox(FB);
+        uint32_t n1, n3, h1, h3;     // nibble-map byte and nibble offset of each ray's texel
+        ps_nibble_of<LOGR, LRZ>(v1, &n1, &h1); ps_nibble_of<LOGR, LRZ>(v3_, &n3, &h3);
+        uint32_t v0 = 0, v2 = 0, n0 = 0, n2 = 0, h0 = 0, h2 = 0, w0 = 0, w2 = 0;
+        if (SHADOW) {
+            v0 = pr_vox(SA); v2 = pr_vox(SB);
+            ps_nibble_of<LOGR, LRZ>(v0, &n0, &h0); ps_nibble_of<LOGR, LRZ>(v2, &n2, &h2);
+            w0 = s_nib[n0]; w2 = s_nib[n2];
+        }
+        const uint32_t w1 = s_nib[n1], w3 = s_nib[n3];
+        uint32_t t1 = __builtin_amdgcn_ubfe(w1, h1, 4u), t3 = __builtin_amdgcn_ubfe(w3, h3, 4u);
+        if (!LRZ) {   // the border texel reads as "mixed", and its byte offset is out of the buffer's range: value 0
+            t1 |= (uint32_t)((int32_t)v1 >> 31) & 15u; t3 |= (uint32_t)((int32_t)v3_ >> 31) & 15u;
+        }
+#ifdef RT_PSTEP_ASM_SEL   // diagnostic variant: the selects of the fetch stage with their masks in SGPR pairs by construction
+        const lanemask m1 = rFA & __ballot(t1 == kNibMixed), m3 = rFB & __ballot(t3 == kNibMixed);   // only a ray in flight on a mixed cube fetches
+        uint32_t t0 = 0, t2 = 0, b0 = 0, b2 = 0;
+        lanemask m0 = 0, m2 = 0;
+        const uint32_t allones = 0xFFFFFFFFu;
+        if (SHADOW) {
+            t0 = __builtin_amdgcn_ubfe(w0, h0, 4u); t2 = __builtin_amdgcn_ubfe(w2, h2, 4u);
+            if (!LRZ) { t0 |= (uint32_t)((int32_t)v0 >> 31) & 15u; t2 |= (uint32_t)((int32_t)v2 >> 31) & 15u; }
+            m0 = rSA & __ballot(t0 == kNibMixed); m2 = rSB & __ballot(t2 == kNibMixed);
+            b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, lm_select(m0, v0, allones), 0, 0);
+        }
+        const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, lm_select(m1, v1, allones), 0, 0);
+        if (SHADOW) b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, lm_select(m2, v2, allones), 0, 0);
+        const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, lm_select(m3, v3_, allones), 0, 0);
+        t1 = lm_select(m1, b1, t1); t3 = lm_select(m3, b3, t3);
+        if (SHADOW) { t0 = lm_select(m0, b0, t0); t2 = lm_select(m2, b2, t2); }
+#else
+        const bool g1 = lm_lane(rFA & __ballot(t1 == kNibMixed)), g3 = lm_lane(rFB & __ballot(t3 == kNibMixed));   // only a ray in flight on a mixed cube fetches
+        uint32_t t0 = 0, t2 = 0, b0 = 0, b2 = 0;
+        bool g0 = false, g2 = false;
+        if (SHADOW) {
+            t0 = __builtin_amdgcn_ubfe(w0, h0, 4u); t2 = __builtin_amdgcn_ubfe(w2, h2, 4u);
+            if (!LRZ) { t0 |= (uint32_t)((int32_t)v0 >> 31) & 15u; t2 |= (uint32_t)((int32_t)v2 >> 31) & 15u; }
+            g0 = lm_lane(rSA & __ballot(t0 == kNibMixed)); g2 = lm_lane(rSB & __ballot(t2 == kNibMixed));
+            b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
+        }
+        const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g1 ? v1 : 0xFFFFFFFFu, 0, 0);
+        if (SHADOW) b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
+        const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g3 ? v3_ : 0xFFFFFFFFu, 0, 0);
+        t1 = g1 ? b1 : t1; t3 = g3 ? b3 : t3;
+        if (SHADOW) { t0 = g0 ? b0 : t0; t2 = g2 ? b2 : t2; }
+#endif
+        if (SHADOW) p_step<false, LOGR, LRZ, CAREFUL>(SA, rSA, nul, nul2, t0, swz, f.lr[0], f.lr[1], f.lr[2]);
+        p_step<true, LOGR, LRZ, CAREFUL>(FA, rFA, zFA, xyFA, t1, swz, f.lr[0], f.lr[1], f.lr[2]);
+        if (SHADOW) p_step<false, LOGR, LRZ, CAREFUL>(SB, rSB, nul, nul2, t2, swz, f.lr[0], f.lr[1], f.lr[2]);
+        p_step<true, LOGR, LRZ, CAREFUL>(FB, rFB, zFB, xyFB, t3, swz, f.lr[0], f.lr[1], f.lr[2]);
+    };
+    // The loop limit (raytrace.comp:109).  The steps of the main loop only count a ray's iterations; every 16th look the wave
+    // asks whether a ray in flight has come within reach of the limit (16 looks = 48 iterations) and, if so, steps with the
+    // counter tested in every iteration until no such ray is left — at most kLimitMargin iterations, no pass in between.  On
+    // terrain this never runs (a ray crosses a unit plane per iteration: <= 969 at R = 256); a 1024^3 region full of value 1
+    // gets there, and so does a ray stalled at a cell boundary far from the origin, where 1e-4 is below the positions' spacing.
+    constexpr uint32_t kLimitMargin = 16u * RT_PATHS_STEPS_PER_CHECK + 4u;
+    auto near_limit = [&]() -> lanemask {
+        return (rSA & __ballot((SA.nk & 0xFFFFu) < kLimitMargin)) | (rFA & __ballot((FA.nk & 0xFFFFu) < kLimitMargin)) |
+               (rSB & __ballot((SB.nk & 0xFFFFu) < kLimitMargin)) | (rFB & __ballot((FB.nk & 0xFFFFu) < kLimitMargin));
+    };
+
     for (;;) {
         uint64_t park;
         for (;;) {
             // a context parks when both its rays have ended; when `threshold` lanes have a parked context the pass runs
-            const uint64_t eA = __ballot(min(SA.nk, FA.nk) >= K_END), eB = __ballot(min(SB.nk, FB.nk) >= K_END);
+            const uint64_t eA = ~(rSA | rFA), eB = ~(rSB | rFB);     // (every lane of the workgroup's waves is active: 1024 threads)
             uint64_t idleA = 0ull, idleB = 0ull;   // lanes whose context is empty for good (no paths left)
             if (exhausted) { idleA = __ballot((PA.st >> 20) == 0u); idleB = __ballot((PB.st >> 20) == 0u); }
             park = (eA & ~idleA) | (eB & ~idleB);
@@ -412,43 +496,15 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             // 4 % of its life in that state and the kernel's last 4 % waiting for its slowest waves: RT_DIAG_WAVE_TIMES)
             if ((uint32_t)__popcll(park) >= (exhausted ? 2u : threshold) || (eA & eB) == ~0ull) break;
             if (COUNT) { d_iters++; d_live += (uint32_t)__popcll(~eA) + (uint32_t)__popcll(~eB); }
-            // ---- one step of all four slots: nibble reads, then byte loads, then the arithmetic ----
+            if (__builtin_expect((looks++ & 15u) == 0u, 0)) {
+                while (__builtin_expect(near_limit() != 0ull, 0)) step_all(std::true_type{}, std::true_type{});
+            }
 #pragma unroll
             for (int rep = 0; rep < RT_PATHS_STEPS_PER_CHECK; rep++) {
-            // compile-time (the loop is unrolled).  The larger regions' steps wait on memory, not on the VALU: every slot steps
-            // in every repetition there (1024^3 region, 4K spp-1024 depth-8 frame: 182 ms against 188 ms with 0x7)
-            const bool shadow_rep = LOGR != 8 || (RT_PATHS_SHADOW_REPS >> rep & 1) != 0;
-            const uint32_t v1 = ps_vox(FA), v3_ = ps_vox(FB);
-            uint32_t n1, n3, h1, h3;     // nibble-map byte and nibble offset of each slot's texel
-            ps_nibble_of<LOGR, LRZ>(v1, &n1, &h1); ps_nibble_of<LOGR, LRZ>(v3_, &n3, &h3);
-            uint32_t v0 = 0, v2 = 0, n0 = 0, n2 = 0, h0 = 0, h2 = 0, w0 = 0, w2 = 0;
-            if (shadow_rep) {
-                v0 = ps_vox(SA); v2 = ps_vox(SB);
-                ps_nibble_of<LOGR, LRZ>(v0, &n0, &h0); ps_nibble_of<LOGR, LRZ>(v2, &n2, &h2);
-                w0 = s_nib[n0]; w2 = s_nib[n2];
-            }
-            const uint32_t w1 = s_nib[n1], w3 = s_nib[n3];
-            uint32_t t1 = __builtin_amdgcn_ubfe(w1, h1, 4u), t3 = __builtin_amdgcn_ubfe(w3, h3, 4u);
-            if (!LRZ) {   // the border texel reads as "mixed", and its byte offset is out of the buffer's range: value 0
-                t1 |= (uint32_t)((int32_t)v1 >> 31) & 15u; t3 |= (uint32_t)((int32_t)v3_ >> 31) & 15u;
-            }
-            const bool g1 = ps_running(FA.nk) && t1 == kNibMixed, g3 = ps_running(FB.nk) && t3 == kNibMixed;
-            uint32_t t0 = 0, t2 = 0, b0 = 0, b2 = 0;
-            bool g0 = false, g2 = false;
-            if (shadow_rep) {
-                t0 = __builtin_amdgcn_ubfe(w0, h0, 4u); t2 = __builtin_amdgcn_ubfe(w2, h2, 4u);
-                if (!LRZ) { t0 |= (uint32_t)((int32_t)v0 >> 31) & 15u; t2 |= (uint32_t)((int32_t)v2 >> 31) & 15u; }
-                g0 = ps_running(SA.nk) && t0 == kNibMixed; g2 = ps_running(SB.nk) && t2 == kNibMixed;
-                b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
-            }
-            const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g1 ? v1 : 0xFFFFFFFFu, 0, 0);
-            if (shadow_rep) b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
-            const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g3 ? v3_ : 0xFFFFFFFFu, 0, 0);
-            t1 = g1 ? b1 : t1; t3 = g3 ? b3 : t3;
-            if (shadow_rep) { t0 = g0 ? b0 : t0; t2 = g2 ? b2 : t2; p_advance<false, 0, LOGR, LRZ>(SA, t0, true, swz, f.lr[0], f.lr[1], f.lr[2]); }
-            p_advance<false, 1, LOGR, LRZ>(FA, t1, true, swz, f.lr[0], f.lr[1], f.lr[2]);
-            if (shadow_rep) p_advance<false, 0, LOGR, LRZ>(SB, t2, true, swz, f.lr[0], f.lr[1], f.lr[2]);
-            p_advance<false, 1, LOGR, LRZ>(FB, t3, true, swz, f.lr[0], f.lr[1], f.lr[2]);
+                // compile-time (the loop is unrolled).  The larger regions' steps wait on memory, not on the VALU: every ray steps
+                // in every repetition there (1024^3 region, 4K spp-1024 depth-8 frame: 182 ms against 188 ms with 0x7)
+                if (LOGR != 8 || (RT_PATHS_SHADOW_REPS >> rep & 1) != 0) step_all(std::true_type{}, std::false_type{});
+                else step_all(std::false_type{}, std::false_type{});
             }
         }
         if (park == 0ull) break;   // nothing in flight, nothing parked, no paths left

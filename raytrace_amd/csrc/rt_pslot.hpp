@@ -131,5 +131,109 @@ __device__ __forceinline__ void p_advance(PSlot& r, uint32_t st, bool enable, ui
     r.sz = *(lds_u32*)(uintptr_t)((iz & kMask) | (swz + 2u * kTab));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 3: the ray of k_paths.  What the step loop needs to know about a ray besides its numbers — is it in flight, along which
+// axis did it step last — are WAVE MASKS (one bit per lane, an SGPR pair each) next to the ray, not flag bits inside a register:
+// testing, merging and keeping them costs scalar instructions, where the flag word cost every slot and step a subtract, two
+// compares, an OR and three selects (VALU issue is what bounds the loop: DESIGN.md 5).  (Per-lane `bool`s carried round the
+// loop do not stay masks: the compiler turns them into 0/1 registers with a v_cndmask to write and a v_cmp to read each.)
+//   run      the ray is in flight: armed and neither on a value 0 (hit), nor outside the region (sky), nor at the loop limit
+//   az, axy  (diffuse rays) the last step went along z / had tx < ty: the face of the hit (raytrace.comp:120-136,166-180)
+// nk = iterations LEFT before the loop limit (2048 for a fresh ray), a plain counter (counting builds: | kFreshInvalid).
+// A ray that never moved (nk == RT_TRACE_LIMIT when it is consumed) is "special" (Q12): a fresh ray on a 0, a NaN direction, a
+// first texel outside the texture.  Whether an ended ray reached the sky is read off its position when the pass consumes it.
+struct PRay {
+    float px, py, pz, ndx, ndy, ndz, lx, ly, lz;
+    uint32_t sx, sy, sz, nk;
+};
+typedef uint64_t lanemask;
+__device__ __forceinline__ bool lm_lane(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }   // this lane's bit (an SGPR-to-VCC copy)
+// m's bit ? a : b as a v_cndmask with the mask in an SGPR pair (never VCC)
+__device__ __forceinline__ uint32_t lm_select(lanemask m, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t pr_vox(const PRay& r) { return r.sx | r.sy | r.sz; }
+template <int LOGR, bool LRZ>
+__device__ __forceinline__ bool pr_outside(float px, float py, float pz, float lrx, float lry, float lrz) {   // :138-145; a NaN is not outside
+    constexpr float half = (float)(1 << (LOGR - 1));
+    return LRZ ? __builtin_fmaxf(__builtin_fmaxf(rtm_abs(px), rtm_abs(py)), rtm_abs(pz)) >= half
+               : __builtin_fmaxf(__builtin_fmaxf(rtm_abs(px - lrx), rtm_abs(py - lry)), rtm_abs(pz - lrz)) >= half;
+}
+
+// One loop iteration (raytrace.comp:109-161) of ray r with the fetched value `st` of its current texel.  The arithmetic is that
+// of p_advance (same q, mod, t, position update and table index — see there); a lane whose ray does not move keeps its numbers.
+// CAREFUL: the wave has a ray within reach of the loop limit (never on terrain: a ray crosses a unit plane per iteration, <= 771
+// at R = 256; a 1024^3 region filled with value 1 gets there) and tests nk itself; otherwise the counter only counts.
+template <bool DIFFUSE, int LOGR, bool LRZ, bool CAREFUL>
+__device__ __forceinline__ void p_step(PRay& r, lanemask& run, lanemask& az, lanemask& axy, uint32_t st, uint32_t swz, float lrx, float lry, float lrz) {
+    constexpr float half = (float)(1 << (LOGR - 1));
+    // (the markers keep the compiler from folding the careful and the plain step group of k_paths into shared blocks with the
+    // counter test in both: two comments in the assembly, no instructions)
+    if (CAREFUL) asm volatile("; careful step" ::: "memory");
+    lanemask go = run & __ballot(st != 0u);
+    if (CAREFUL) go &= __ballot((r.nk & 0xFFFFu) != 0u);
+    uint32_t sb;                                                 // float((1 << st) / 2) = (st << 23) + bits(0.5), in one instruction
+    asm("v_lshl_add_u32 %0, %1, 23, 0.5" : "=v"(sb) : "v"(st));  // (the compiler shifts once and adds twice: 7.3 issue cycles against 5.4)
+    const float sz = f_bits(sb), is = f_bits(0x7F000000u - sb);  // is == 1 / sz exactly
+    const float ux = r.px + half, uy = r.py + half, uz = r.pz + half;
+    float qx, qy, qz;                                            // (pos + R/2) * muls, :94-98,119
+    if (!LRZ) {
+        qx = f_bits(u_bits(ux) ^ (u_bits(r.ndx) & 0x80000000u));
+        qy = f_bits(u_bits(uy) ^ (u_bits(r.ndy) & 0x80000000u));
+        qz = f_bits(u_bits(uz) ^ (u_bits(r.ndz) & 0x80000000u));
+    } else {
+        qx = f_bits((u_bits(ux) & 0x7FFFFFFFu) | (u_bits(r.ndx) & 0x80000000u));
+        qy = f_bits((u_bits(uy) & 0x7FFFFFFFu) | (u_bits(r.ndy) & 0x80000000u));
+        qz = f_bits((u_bits(uz) & 0x7FFFFFFFu) | (u_bits(r.ndz) & 0x80000000u));
+    }
+    const float mx = __builtin_fmaf(-sz, rtm_floor(qx * is), qx);   // mod(q, sz): both products exact
+    const float my = __builtin_fmaf(-sz, rtm_floor(qy * is), qy);
+    const float mz = __builtin_fmaf(-sz, rtm_floor(qz * is), qz);
+    const float tx = (0.0001f + mx) * r.lx, ty = (0.0001f + my) * r.ly, tz = (0.0001f + mz) * r.lz;   // :119
+    const float t = __builtin_fminf(__builtin_fminf(tx, ty), tz);  // :120-136 (see p_advance)
+    if (DIFFUSE) { az = (go & __ballot(tz == t)) | (az & ~go); axy = (go & __ballot(tx < ty)) | (axy & ~go); }
+#ifdef RT_PSTEP_TE_SELECT   // diagnostic variant: selects instead of the exec mask
+    {
+        const bool gol = lm_lane(go);
+        const float te = gol ? t : 0.0f;
+        r.px = __builtin_fmaf(-r.ndx, te, r.px); r.py = __builtin_fmaf(-r.ndy, te, r.py); r.pz = __builtin_fmaf(-r.ndz, te, r.pz);
+        r.nk -= gol ? 1u : 0u;
+    }
+#else
+    // pos += dir * t (:121-135) and the iteration count, for the lanes that move: under their exec mask instead of a select per
+    // value — two scalar instructions around four full-rate VALU ones.  (The compiler would emit v_cndmask t / 0 and 0 / 1.)
+    {
+        lanemask saved;
+        asm("s_and_saveexec_b64 %[sv], %[go]\n\t"
+            "v_fma_f32 %[px], -%[dx], %[t], %[px]\n\t"
+            "v_fma_f32 %[py], -%[dy], %[t], %[py]\n\t"
+            "v_fma_f32 %[pz], -%[dz], %[t], %[pz]\n\t"
+            "v_add_u32_e32 %[nk], -1, %[nk]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [px] "+v"(r.px), [py] "+v"(r.py), [pz] "+v"(r.pz), [nk] "+v"(r.nk), [sv] "=&s"(saved)
+            : [go] "s"(go), [t] "v"(t), [dx] "v"(r.ndx), [dy] "v"(r.ndy), [dz] "v"(r.ndz)
+            : "scc");
+    }
+#endif
+    run = go & ~__ballot(pr_outside<LOGR, LRZ>(r.px, r.py, r.pz, lrx, lry, lrz));
+    // table words of the next fetch's texel (:137), as in p_advance
+    constexpr float four_half = 4.0f * half;
+    constexpr uint32_t kMask = swz_bytes<LOGR>() - 4u, kTab = swz_bytes<LOGR>();
+    float x4 = __builtin_fmaf(r.px, 4.0f, four_half), y4 = __builtin_fmaf(r.py, 4.0f, four_half), z4 = __builtin_fmaf(r.pz, 4.0f, four_half);
+    if (!LRZ) {
+        constexpr float four_r = 8.0f * half, inv_four_r = 1.0f / four_r;
+        x4 = __builtin_fmaf(-four_r, rtm_floor(x4 * inv_four_r), x4);
+        y4 = __builtin_fmaf(-four_r, rtm_floor(y4 * inv_four_r), y4);
+        z4 = __builtin_fmaf(-four_r, rtm_floor(z4 * inv_four_r), z4);
+    }
+    const uint32_t ix = (uint32_t)(int)x4, iy = (uint32_t)(int)y4, iz = (uint32_t)(int)z4;
+    r.sx = *(lds_u32*)(uintptr_t)((ix & kMask) | swz);
+    r.sy = *(lds_u32*)(uintptr_t)((iy & kMask) | (swz + kTab));
+    r.sz = *(lds_u32*)(uintptr_t)((iz & kMask) | (swz + 2u * kTab));
+    if (CAREFUL) asm volatile("; careful step end" ::: "memory");
+}
+
 }  // namespace pslot
 }  // namespace rtd

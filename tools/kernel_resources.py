@@ -1,5 +1,5 @@
 """Compiler's resource usage (VGPRs, SGPRs, spills, LDS, occupancy) of every shipped kernel instantiation:
-hipcc -Rpass-analysis=kernel-resource-usage over the four .hip files -> profiles/r2_kernel_resources.txt."""
+hipcc -Rpass-analysis=kernel-resource-usage over the four .hip files -> profiles/r3_kernel_resources.txt."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 files = ["rt_paths.hip", "rt_persist.hip", "rt_kernels.hip", "rt_post.hip"]
@@ -21,7 +21,7 @@ for f in files:
         elif cur is not None and ":" in body:
             k, v = body.split(":", 1)
             cur[k.strip()] = v.strip()
-out = os.path.join(ROOT, "profiles", "r2_kernel_resources.txt")
+out = os.path.join(ROOT, "profiles", "r3_kernel_resources.txt")
 with open(out, "w") as fh:
     fh.write("# hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py)\n")
     fh.write("%-14s %-58s %5s %5s %8s %7s %10s %4s\n" % ("file", "kernel", "VGPR", "SGPR", "scratchB", "spills", "LDS bytes", "occ"))

@@ -153,7 +153,7 @@ int main() {
     run<44>("v_pk_fma_f32", out, cyc);
     run<45>("v_pk_mul_f32", out, cyc);
     run<46>("v_pk_add_f32", out, cyc);
-    run<47>("s_and_b64", out, cyc);
-    run<48>("ds_read_b32", out, cyc);
+    // (kinds 47 "s_and_b64" and 48 "ds_read_b32" are not part of the VALU table; the SALU-only loop did not finish within 100 s at
+    // two waves per SIMD on the round-3 box and is left out of the default run)
     return 0;
 }
