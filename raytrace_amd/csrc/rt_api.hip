@@ -82,8 +82,7 @@ struct RtContext {
     uint32_t* pcursor = nullptr;   // [0, kCursorWords) path cursors (one per XCD group), [kCursorWords] worklist count
     uint32_t* pstack = nullptr;
     uint32_t* worklist = nullptr;
-    float *phx = nullptr, *phy = nullptr, *phz = nullptr;
-    uint32_t* pinfo = nullptr;
+    float4* phit = nullptr;        // primary-hit records of the worklist (rtd::PrimaryArgs::phit)
     float4* sphere_lut = nullptr;
     float4* sun_lut = nullptr;
     float4* dif_lut = nullptr;
@@ -390,15 +389,15 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= 4096) c->persist_chunk = (uint32_t)v & ~63u; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
-    if (c->persist_threshold == 0)   // measured optima (k_paths: 32 lanes with a parked context, three steps between looks: 24 4.46 ms, 32 4.39, 36 4.39-4.41, 40 4.43, 44 4.51)
-        c->persist_threshold = c->persist_version == 4 ? 36u : 32u;
+    if (c->persist_threshold == 0)   // measured optima.  k_paths (lanes with a parked context, three steps between looks), round 3 after the
+                                     // mask rework, same box: 24 4.28 ms per headline launch, 28 4.22, 32 4.17, 36 4.06-4.15, 40 4.08-4.14, 44 4.12, 48 4.27
+        c->persist_threshold = c->persist_version == 1 ? 32u : 36u;
     if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 16u;   // k_seq: waiting contexts that trigger the re-arm block
     if (c->kernel == RT_KERNEL_PERSISTENT) {
         RT_HIP_CREATE(dev_alloc(c, &c->pcursor, kCursorWords + 1));   // 8 cursor lines + the worklist count
         RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)4 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));   // up to 3 paths per lane
         RT_HIP_CREATE(dev_alloc(c, &c->worklist, (size_t)c->npix_pad));
-        RT_HIP_CREATE(dev_alloc(c, &c->phx, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->phy, (size_t)c->npix_pad));
-        RT_HIP_CREATE(dev_alloc(c, &c->phz, (size_t)c->npix_pad)); RT_HIP_CREATE(dev_alloc(c, &c->pinfo, (size_t)c->npix_pad));
+        RT_HIP_CREATE(dev_alloc(c, &c->phit, (size_t)c->npix_pad));
         RT_HIP_CREATE(dev_alloc(c, &c->sphere_lut, (size_t)65536));
         RT_HIP_CREATE(dev_alloc(c, &c->sun_lut, (size_t)2 * 65536));
         RT_HIP_CREATE(dev_alloc(c, &c->dif_lut, (size_t)4 * 6 * 65536));
@@ -621,7 +620,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         if (e == hipSuccess && cache) {
             LaunchTimer t(ctx, 1);
             rtd::PrimaryArgs pr{};
-            pr.phx = ctx->phx; pr.phy = ctx->phy; pr.phz = ctx->phz; pr.pinfo = ctx->pinfo;
+            pr.phit = ctx->phit;
             pr.worklist = ctx->worklist; pr.wl_count = ctx->pcursor + kCursorWords; pr.acc = ctx->pacc; pr.counters = ctx->d_counters;
             e = rtd::launch_primary(scene_of(ctx), f, planes_of(ctx), pr, count, ctx->primary_version, ctx->num_cus, ctx->stream);
         }
@@ -643,7 +642,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 pa.cursor = ctx->pcursor; pa.worklist = ctx->worklist; pa.wl_count = ctx->pcursor + kCursorWords;
                 pa.npix_pad = ctx->npix_pad; pa.sample0 = s0; pa.nsamples = ns; pa.threshold = ctx->persist_threshold; pa.rmin = ctx->persist_rmin; pa.chunk = ctx->persist_chunk;
                 pa.nthreads = (uint32_t)ctx->num_cus * 1024u; pa.stack = ctx->pstack;
-                pa.phx = ctx->phx; pa.phy = ctx->phy; pa.phz = ctx->phz; pa.pinfo = ctx->pinfo;
+                pa.phit = ctx->phit;
                 pa.sun_lut = ctx->sun_lut; pa.dif_lut = ctx->dif_lut;
                 pa.pl = ctx->ppl; pa.counters = ctx->d_counters;
                 if (e == hipSuccess) {

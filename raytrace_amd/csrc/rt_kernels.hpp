@@ -48,8 +48,8 @@ struct ShadeArgs {
 
 // k_primary / k_primary2 (rt_persist.hip): primary prepass.  Arrays are indexed by worklist slot (acc: by local pixel).
 struct PrimaryArgs {
-    float *phx, *phy, *phz;     // primary hit position (with the 0.001 face offset) of queued pixels
-    uint32_t* pinfo;            // material[20:0] | face id << 24
+    float4* phit;               // per queued pixel, ONE 16-byte record: primary hit position (with the 0.001 face offset) and, as bits of .w,
+                                // face id << 28 | gl_WorkGroupID.y * 8 << 14 | gl_WorkGroupID.x * 8 (the noise_offset terms, raytrace.comp:304)
     uint32_t* worklist;         // local pixel ids that need shadow/diffuse rays
     uint32_t* wl_count;         // zero before launch
     float4* acc;                // (unused by the prepass since it stores the lighting of the pixels it finishes itself)
@@ -70,8 +70,7 @@ struct PersistArgs {
     uint32_t chunk;             // paths per cursor atomic; 0 = the default (128)
     uint32_t nthreads;          // grid size in threads (stride of the albedo stack)
     uint32_t* stack;            // [2][(depth-1)][nthreads] packed material of surface j+1 (only touched when depth >= 2; k_persist uses half)
-    const float *phx, *phy, *phz;   // CACHE: primary hit per local pixel
-    const uint32_t* pinfo;
+    const float4* phit;         // CACHE: the primary prepass' record per worklist slot (PrimaryArgs::phit): one load per new path
     const float4* sun_lut;      // [2*65536] per-frame shadow-ray table: direction, 1/|direction|
     const float4* dif_lut;      // [4*6*65536] diffuse-ray table, one 64-byte line per (face, noise byte pair): dir, normalized dir, 1/|dir|, per-frame sky(dir)
     PathLight* pl;              // [nsamples * nwork] light of each path (one 12-byte store per path)

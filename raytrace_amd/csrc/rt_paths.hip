@@ -49,7 +49,8 @@
 // benchmark scene against the diffuse ray's 7.9) and its slot then idles until the diffuse ray ends; stepping it in two of three
 // repetitions removes a sixth of the loop's instructions and rarely lengthens a level.  Same-box timings (tools/abn.sh) with
 // the merged pass: 3 steps / 0x3 4.41 ms per launch, 3 / 0x7 4.53, 4 / 0x7 4.47, 4 / 0xF 4.56, 5 / 0x15 4.46, 5 / 0x0F 4.54,
-// 6 / 0x1B 4.88.
+// 6 / 0x1B 4.88.  Round 3 (wave masks, cheaper looks), same box: 3 / 0x3 4.06-4.08 ms, 4 / 0x7 4.09-4.14, 4 / 0xB 4.08-4.11, 5 / 0x17 4.15-4.18,
+// 5 / 0xF 4.16-4.19, 2 / 0x1 4.30, 3 / 0x7 4.25.
 #ifndef RT_PATHS_STEPS_PER_CHECK
 #define RT_PATHS_STEPS_PER_CHECK 3
 #endif
@@ -275,8 +276,9 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         const bool hit = cont && kind == 0u;
         const float4 skyv = a.dif_lut[air ? 4u * Pent + 3u : 0u];   // :331-332 / :343-345, tabulated per frame; Pent = the entry F walked
         const uint32_t matv = sc.mat[(hit && !(!LRZ && ps_border(Fvox))) ? Fvox : 0u];   // the hit texel is the texel of the last fetch (:150-154); border: 0
-        const uint32_t info = a.pinfo[nw];
-        const float ox = a.phx[nw], oy = a.phy[nw], oz = a.phz[nw];
+        const float4 ph = a.phit[nw];       // the prepass' record of the new path's pixel: one 16-byte load
+        const uint32_t info = u_bits(ph.w);
+        const float ox = ph.x, oy = ph.y, oz = ph.z;
         // noise_offset of the new path (:298-304) and its noise_value texel (:324, :336); one integer lookup serves every level
         // (Q5; tests/test_math_contract.py::test_noise_value_texel_is_level_independent)
         const uint32_t seed = (f.seed + a.sample0 + nsb) % (uint32_t)RT_NOISE_BYTES;

@@ -114,10 +114,10 @@ __global__ __launch_bounds__(256) void k_primary(Scene sc, Frame f, Planes pl, P
         if (queue) {
             const uint32_t w = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             a.worklist[w] = lp;
-            a.phx[w] = qpos.x; a.phy[w] = qpos.y; a.phz[w] = qpos.z;
             // face id, and the noise_offset terms gl_WorkGroupID.xy * 8 of the pixel (raytrace.comp:304)
-            a.pinfo[w] = (qnormal << 28) | (owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE) << 14 |
-                         (owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE);
+            const uint32_t info = (qnormal << 28) | (owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE) << 14 |
+                                  (owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE);
+            a.phit[w] = make_float4(qpos.x, qpos.y, qpos.z, __uint_as_float(info));
         }
     }
     if (COUNT) {
@@ -224,9 +224,9 @@ __global__ __launch_bounds__(1024) void k_primary2(Scene sc, Frame f, Planes pl,
         if (queue) {
             const uint32_t w = s_off[wiw] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             a.worklist[w] = lp;
-            a.phx[w] = qpos.x; a.phy[w] = qpos.y; a.phz[w] = qpos.z;
-            a.pinfo[w] = (qnormal << 28) | (owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE) << 14 |
-                         (owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE);
+            const uint32_t info = (qnormal << 28) | (owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE) << 14 |
+                                  (owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE);
+            a.phit[w] = make_float4(qpos.x, qpos.y, qpos.z, __uint_as_float(info));
         }
     }
     if (COUNT) {
@@ -491,8 +491,9 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                         uint32_t wgx8 = 0, wgy8 = 0;
                         bool ok = true;
                         if (CACHE) {
-                            const uint32_t info = a.pinfo[w];
-                            sfx = a.phx[w]; sfy = a.phy[w]; sfz = a.phz[w];
+                            const float4 ph = a.phit[w];
+                            const uint32_t info = __float_as_uint(ph.w);
+                            sfx = ph.x; sfy = ph.y; sfz = ph.z;
                             snormal = info >> 28; wgx8 = info & 0x3FFFu; wgy8 = (info >> 14) & 0x3FFFu;
                         } else {
                             PixelId pix = pixel_of_local(f, w);

@@ -301,8 +301,9 @@ __global__ __launch_bounds__(1024) void k_seq(Scene sc, Frame f, Planes pl, Pers
                         uint32_t sb = chunk_sb, w = chunk_w + rank;
                         while (w >= chunk_nw) { w -= chunk_nw; sb++; }
                         w += chunk_w0;   // worklist slot
-                        const uint32_t info = a.pinfo[w];
-                        sfx = a.phx[w]; sfy = a.phy[w]; sfz = a.phz[w];
+                        const float4 ph = a.phit[w];
+                        const uint32_t info = __float_as_uint(ph.w);
+                        sfx = ph.x; sfy = ph.y; sfz = ph.z;
                         snormal = info >> 28;
                         const uint32_t wgx8 = info & 0x3FFFu, wgy8 = (info >> 14) & 0x3FFFu;
                         P.item = sb * nwork + w;

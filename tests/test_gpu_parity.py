@@ -589,6 +589,65 @@ def test_deep_paths_on_the_larger_regions(blue_noise, region512, region1024, reg
                 assert gcn.as_dict() == cached
 
 
+def test_far_travelled_window_reaches_the_loop_limit(blue_noise):
+    """raytrace.comp:109 — far from the origin the 1e-4 nudge of :119 drops below the spacing of the positions (2^-12 at
+    |x| = 2048), rays stall at cell boundaries and run into the 2048-iteration limit (a quarter of this frame's rays; the
+    reference's own arithmetic, restated by the oracle).  k_paths counts iterations without testing the counter in its main
+    loop and switches to tested steps when a ray comes within reach of the limit (rt_paths.hip): planes, the exact counters
+    and the number of limit exits must be the oracle's, on k_persist as well."""
+    lr = (2048, 0, 0)
+    mats, mine = world.toroidal_region(lr)
+    u = _uniforms(origin=(lr[0] - 30.0, lr[1] - 128.0, lr[2] + 100.0), pitch=-0.2, sun=0.3, seed=3, lr=lr)
+    W, H, spp, depth = 64, 40, 2, 3
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    assert ccn.limit_exits > 1000
+    cached = _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
+    for kernel, flags in ((abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY), (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS),
+                          (abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS)):
+        cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=kernel, flags=flags)
+        with render.Context(cfg) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(u)
+            ctx.sync()
+            assert ctx.kernel_in_use() == kernel
+            gpu, gcn = ctx.readback_all(), ctx.counters()
+        if flags == abi.RT_FLAG_COUNTERS:
+            _compare(gpu, cpu, gcn, ccn)
+        else:
+            _compare(gpu, cpu)
+            if flags & abi.RT_FLAG_COUNTERS:
+                assert gcn.as_dict() == cached and gcn.limit_exits > 1000
+
+
+def test_loop_limit_in_a_region_of_unit_cells(blue_noise, native_built):
+    """The loop limit with lr = 0: a 1024^3 region whose empty space carries minefield value 1 throughout (unit steps — a valid
+    minefield, just not a packed one) above a solid floor.  Diffuse rays leaving the floor diagonally need ~3000 iterations to
+    cross the region and stop at 2048 (Q8: a non-air hit with material 0): k_paths<., 1, 10, true> against the oracle."""
+    R = 1024
+    mine = np.ones((R, R, R), dtype=np.uint8)
+    mats = np.zeros((R, R, R), dtype=np.uint32)
+    mine[:16] = 0
+    mats[:16] = world.material_pack(2)
+    u = po.camera_uniforms((-490.0, -490.0, -480.0), np.pi / 4, -0.5, 0.2, 9)
+    W, H, spp, depth = 32, 16, 4, 2
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth, region=R)
+    assert ccn.limit_exits > 50
+    cached = _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn, region=R)
+    for flags in (abi.RT_FLAG_CACHE_PRIMARY, abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS):
+        cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=abi.RT_KERNEL_PATHS, flags=flags, region=R)
+        with render.Context(cfg) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(u)
+            ctx.sync()
+            assert ctx.kernel_in_use() == abi.RT_KERNEL_PATHS
+            gpu, gcn = ctx.readback_all(), ctx.counters()
+        _compare(gpu, cpu)
+        if flags & abi.RT_FLAG_COUNTERS:
+            assert gcn.as_dict() == cached and gcn.limit_exits == ccn.limit_exits
+
+
 C5 = (3840, 2160, 1024, 8)     # BASELINE.json config 5 on the 1024^3 region
 
 

@@ -4,8 +4,12 @@ TAG=$1; ARGS=$2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmcm_$TAG; rm -rf $OUT; mkdir -p $OUT
 i=0
-# NB: the TA_*, TD_* and TCP_GATE_EN*/TCP_PENDING_STALL sets never finished on this pool (each pass ran into its 240 s limit);
-# only the two sets below return.
+# NB (diagnosed in round 3 from the round-2 logs, gpurun_out/pmcm_paths/run{1,2,5}.log): the passes that asked for four TA_* /
+# TD_* / TCP_GATE_EN* / TCP_PENDING_STALL counters at once did not hang the GPU — rocprofv3 refused the set before any kernel ran
+# ("rocprofiler_create_counter_config ... error code 38: Request exceeds the capabilities of the hardware to collect": more
+# counters of one block than it has registers), aborted (signal 6) inside its own tool library, and its signal handler then sat
+# until the 240 s limit killed the process.  No dispatch had been made, nothing was left on the device.  Such counters have to
+# be asked for in smaller sets (one or two per block and pass); the two sets below fit and return.
 for P in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum" \
          "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
   i=$((i+1))

@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 passes of tools/profile_r2.sh into one JSON: per workload and kernel, per-launch averages of every
+"""Condense the rocprofv3 passes of tools/profile_r3.sh into one JSON: per workload and kernel, per-launch averages of every
 counter plus the derived figures bench.py attaches to its `roofline` record.  usage: pmc_to_json.py <prof dir>"""
 import csv, glob, hashlib, json, os, re, sys, collections
 
@@ -42,12 +42,20 @@ def stats(tagdir):
     return out
 
 
-res = {"kernel_source_sha16": source_sha16(), "tool": "tools/profile_r2.sh (rocprofv3, one --pmc set per pass)", "workloads": {}}
+res = {"kernel_source_sha16": source_sha16(), "tool": "tools/profile_r3.sh (rocprofv3, one --pmc set per pass)", "workloads": {}}
+# issue cost of the step loop's instruction mix (tools/isa_hist.py), if it was taken on these very sources
+CPI = None
+try:
+    _h = json.load(open(os.path.join(ROOT, "profiles", "r3_step_loop_isa_hist.json")))
+    if _h.get("kernel_source_sha16") == res["kernel_source_sha16"]:
+        CPI = float(_h["cycles_per_valu_inst"])
+except Exception:
+    pass
 for tag, wname in WORK.items():
     per = collections.defaultdict(dict)
     st = stats(os.path.join(prof, tag + "_stats"))
     for (k, full), v in st.items():
-        if re.search(r"k_paths<true|k_persist2?<\d+, (true|false), true,|k_primary2<\d+, (true|false), true>|k_accumulate_paths<false>", full):
+        if re.search(r"k_paths<true|k_persist<\d+, (true|false), true,|k_primary2<\d+, (true|false), true>|k_accumulate_paths<false>", full):
             continue   # counting builds run once outside the timed region
         if k in ("k_paths", "k_persist", "k_primary2", "k_accumulate_paths"):
             per[k]["instantiation"] = full
@@ -80,6 +88,10 @@ for tag, wname in WORK.items():
                 # wave64 instruction for fma/mul/add/and/or/lshr/mov, 3.4 for select/compare/convert/floor/bfi/min3/packed
                 "pipe_busy_if_all_2cyc": round(g("SQ_INSTS_VALU") * 2.0 / (SIMDS * cycles), 3),
                 "pipe_busy_if_all_3.4cyc": round(g("SQ_INSTS_VALU") * 3.4 / (SIMDS * cycles), 3),
+                # ... and at the measured cost of the step loop's own instruction mix (profiles/r3_step_loop_isa_hist.json:
+                # per-opcode counts of the step group x the micro-benchmark's issue cost), k_paths only
+                "pipe_busy_weighted": round(g("SQ_INSTS_VALU") * CPI / (SIMDS * cycles), 3) if (CPI and k == "k_paths") else None,
+                "cycles_per_valu_inst": CPI if k == "k_paths" else None,
                 "exec_lane_fill": round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU")), 3) if g("SQ_THREAD_CYCLES_VALU") else None,
                 "wait_any_frac": round(g("SQ_WAIT_ANY") / wc, 3), "wait_inst_any_frac": round(g("SQ_WAIT_INST_ANY") / wc, 3),
                 "active_inst_any_frac": round(g("SQ_ACTIVE_INST_ANY") / wc, 3),
