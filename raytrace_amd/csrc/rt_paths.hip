@@ -355,8 +355,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         const uint32_t se = Pent & 0xFFFFu;
         const bool newface = start && snormal != Pent >> 16;
         const uint32_t di = newface ? 4u * ((snormal << 16) | se) : 0u;
-        const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
         const uint32_t si = getnew ? 2u * se : 0u;
+        // (1 / |direction| comes from the tables too: computing the six IEEE divisions here instead of the two extra 16-byte loads
+        // was measured at +3.0 % on the headline launch, +2.5 % on C4, +1.7 % on C5 — profiles/r3_kpaths_variants_c.txt)
+        const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
         const float4 sd = a.sun_lut[si], sl = a.sun_lut[si + 1u];
         // both rays of the level (:324-330 / :336-342) from the surface point (sfx, sfy, sfz) with face id snormal: head of
         // trace_ray (:83-107)
@@ -438,23 +440,6 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         if (!LRZ) {   // the border texel reads as "mixed", and its byte offset is out of the buffer's range: value 0
             t1 |= (uint32_t)((int32_t)v1 >> 31) & 15u; t3 |= (uint32_t)((int32_t)v3_ >> 31) & 15u;
         }
-#ifdef RT_PSTEP_ASM_SEL   // diagnostic variant: the selects of the fetch stage with their masks in SGPR pairs by construction
-        const lanemask m1 = rFA & __ballot(t1 == kNibMixed), m3 = rFB & __ballot(t3 == kNibMixed);   // only a ray in flight on a mixed cube fetches
-        uint32_t t0 = 0, t2 = 0, b0 = 0, b2 = 0;
-        lanemask m0 = 0, m2 = 0;
-        const uint32_t allones = 0xFFFFFFFFu;
-        if (SHADOW) {
-            t0 = __builtin_amdgcn_ubfe(w0, h0, 4u); t2 = __builtin_amdgcn_ubfe(w2, h2, 4u);
-            if (!LRZ) { t0 |= (uint32_t)((int32_t)v0 >> 31) & 15u; t2 |= (uint32_t)((int32_t)v2 >> 31) & 15u; }
-            m0 = rSA & __ballot(t0 == kNibMixed); m2 = rSB & __ballot(t2 == kNibMixed);
-            b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, lm_select(m0, v0, allones), 0, 0);
-        }
-        const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, lm_select(m1, v1, allones), 0, 0);
-        if (SHADOW) b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, lm_select(m2, v2, allones), 0, 0);
-        const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, lm_select(m3, v3_, allones), 0, 0);
-        t1 = lm_select(m1, b1, t1); t3 = lm_select(m3, b3, t3);
-        if (SHADOW) { t0 = lm_select(m0, b0, t0); t2 = lm_select(m2, b2, t2); }
-#else
         const bool g1 = lm_lane(rFA & __ballot(t1 == kNibMixed)), g3 = lm_lane(rFB & __ballot(t3 == kNibMixed));   // only a ray in flight on a mixed cube fetches
         uint32_t t0 = 0, t2 = 0, b0 = 0, b2 = 0;
         bool g0 = false, g2 = false;
@@ -469,7 +454,6 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g3 ? v3_ : 0xFFFFFFFFu, 0, 0);
         t1 = g1 ? b1 : t1; t3 = g3 ? b3 : t3;
         if (SHADOW) { t0 = g0 ? b0 : t0; t2 = g2 ? b2 : t2; }
-#endif
         if (SHADOW) p_step<false, LOGR, LRZ, CAREFUL>(SA, rSA, nul, nul2, t0, swz, f.lr[0], f.lr[1], f.lr[2]);
         p_step<true, LOGR, LRZ, CAREFUL>(FA, rFA, zFA, xyFA, t1, swz, f.lr[0], f.lr[1], f.lr[2]);
         if (SHADOW) p_step<false, LOGR, LRZ, CAREFUL>(SB, rSB, nul, nul2, t2, swz, f.lr[0], f.lr[1], f.lr[2]);

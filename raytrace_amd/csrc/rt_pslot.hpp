@@ -148,12 +148,6 @@ struct PRay {
 };
 typedef uint64_t lanemask;
 __device__ __forceinline__ bool lm_lane(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }   // this lane's bit (an SGPR-to-VCC copy)
-// m's bit ? a : b as a v_cndmask with the mask in an SGPR pair (never VCC)
-__device__ __forceinline__ uint32_t lm_select(lanemask m, uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
-    return r;
-}
 __device__ __forceinline__ uint32_t pr_vox(const PRay& r) { return r.sx | r.sy | r.sz; }
 template <int LOGR, bool LRZ>
 __device__ __forceinline__ bool pr_outside(float px, float py, float pz, float lrx, float lry, float lrz) {   // :138-145; a NaN is not outside
