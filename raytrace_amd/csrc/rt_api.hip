@@ -29,6 +29,12 @@ const size_t kBytesPerPixel[RT_BUF_COUNT] = {8, 2, 1, 4, 4, 4, 16, 16, 4, 4};
 }  // namespace
 
 constexpr size_t kCursorWords = 8 * 32;   // path cursors of the persistent kernels: one word per XCD group, each on its own 128-byte line
+// A cursor SET = the eight cursor lines + the worklist count on a line of its own.  There are two: frame n works on set n & 1 while
+// its prepass clears the other one for frame n + 1 (no memset in front of every frame).
+constexpr size_t kCursorSetWords = kCursorWords + 32;
+// RT_KERNEL_DEFAULT: launches of at least this many pixel-samples run on k_paths, smaller ones on k_persist (measured crossover,
+// round 3, same box: 1080p spp 1 (2.1 M) 0.351 against 0.348 ms per frame, spp 2 (4.1 M) 0.409 against 0.442; 1024^2 spp 1 0.252 against 0.229)
+constexpr uint64_t kPathsCrossover = 3ull << 20;
 
 struct RtContext {
     RtConfig cfg{};
@@ -79,7 +85,9 @@ struct RtContext {
     float4* acc = nullptr;
     uint32_t* ctrl = nullptr;     // per batch: [RT_MAX_DEPTH+2] pair counts, then [RT_MAX_DEPTH+2] cursors
     // persistent kernel state
-    uint32_t* pcursor = nullptr;   // [0, kCursorWords) path cursors (one per XCD group), [kCursorWords] worklist count
+    uint32_t* pcursor = nullptr;   // two cursor sets: [0, kCursorWords) path cursors (one per XCD group), [kCursorWords] worklist count
+    int cursor_set = 0;            // the set the next frame works on
+    bool cursor_set_clean[2] = {false, false};   // all zero (by the create-time memset or by the previous frame's prepass)
     uint32_t* pstack = nullptr;
     uint32_t* worklist = nullptr;
     float4* phit = nullptr;        // primary-hit records of the worklist (rtd::PrimaryArgs::phit)
@@ -394,7 +402,9 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         c->persist_threshold = c->persist_version == 1 ? 32u : 36u;
     if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 16u;   // k_seq: waiting contexts that trigger the re-arm block
     if (c->kernel == RT_KERNEL_PERSISTENT) {
-        RT_HIP_CREATE(dev_alloc(c, &c->pcursor, kCursorWords + 1));   // 8 cursor lines + the worklist count
+        RT_HIP_CREATE(dev_alloc(c, &c->pcursor, 2 * kCursorSetWords));   // two sets of 8 cursor lines + the worklist count
+        RT_HIP_CREATE(hipMemset(c->pcursor, 0, 2 * kCursorSetWords * sizeof(uint32_t)));
+        c->cursor_set_clean[0] = c->cursor_set_clean[1] = true;
         RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)4 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));   // up to 3 paths per lane
         RT_HIP_CREATE(dev_alloc(c, &c->worklist, (size_t)c->npix_pad));
         RT_HIP_CREATE(dev_alloc(c, &c->phit, (size_t)c->npix_pad));
@@ -616,13 +626,23 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("launch_mega: ") + hipGetErrorString(e));
     } else if (ctx->kernel == RT_KERNEL_PERSISTENT) {
         const bool cache = (ctx->cfg.flags & RT_FLAG_CACHE_PRIMARY) != 0;
-        hipError_t e = hipMemsetAsync(ctx->pcursor, 0, (kCursorWords + 1) * sizeof(uint32_t), ctx->stream);
+        // this frame's cursor set: clean already if the previous frame's prepass cleared it, otherwise cleared here
+        const int set = ctx->cursor_set;
+        uint32_t* const cur = ctx->pcursor + (size_t)set * kCursorSetWords;
+        uint32_t* const nxt = ctx->pcursor + (size_t)(set ^ 1) * kCursorSetWords;
+        hipError_t e = hipSuccess;
+        if (!ctx->cursor_set_clean[set]) e = hipMemsetAsync(cur, 0, kCursorSetWords * sizeof(uint32_t), ctx->stream);
+        ctx->cursor_set_clean[set] = false;
+        ctx->cursor_set = set ^ 1;
+        const bool prepass_clears = cache && ctx->primary_version == 2;
         if (e == hipSuccess && cache) {
             LaunchTimer t(ctx, 1);
             rtd::PrimaryArgs pr{};
             pr.phit = ctx->phit;
-            pr.worklist = ctx->worklist; pr.wl_count = ctx->pcursor + kCursorWords; pr.acc = ctx->pacc; pr.counters = ctx->d_counters;
+            pr.worklist = ctx->worklist; pr.wl_count = cur + kCursorWords; pr.acc = ctx->pacc; pr.counters = ctx->d_counters;
+            pr.zero_words = prepass_clears ? nxt : nullptr; pr.zero_count = (uint32_t)kCursorSetWords;
             e = rtd::launch_primary(scene_of(ctx), f, planes_of(ctx), pr, count, ctx->primary_version, ctx->num_cus, ctx->stream);
+            ctx->cursor_set_clean[set ^ 1] = prepass_clears && e == hipSuccess && ctx->npix_pad != 0;
         }
         // the two per-frame tables depend on the sun vector and colour only: rebuilt when those change (bit compare)
         float lut_key[6] = {f.sunangle[0], f.sunangle[1], f.sunangle[2], f.sunlight[0], f.sunlight[1], f.sunlight[2]};
@@ -635,11 +655,16 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         }
         if (!cache || ctx->cfg.depth >= 1) {
             const uint32_t spp = (uint32_t)ctx->cfg.spp, B = ctx->persist_batch;
+            // one sample per pixel (the reference's own frames): k_persist and k_paths store the pixel's lighting themselves, no
+            // light records and no accumulate launch (raytrace.comp:352-356 has no accumulation either)
+            const bool small1 = ctx->paths_by_size && (uint64_t)ctx->npix_pad < kPathsCrossover;   // spp 1: the launch goes to k_persist
+            const bool on_paths = ctx->persist_version == 3 && cache && !small1;
+            const bool direct = spp == 1u && ctx->persist_version != 4 && (!on_paths || rtd::launch_paths_direct_ok(f));
             for (uint32_t s0 = 0; s0 < spp && e == hipSuccess; s0 += B) {
                 const uint32_t ns = spp - s0 < B ? spp - s0 : B;
-                if (s0 != 0) e = hipMemsetAsync(ctx->pcursor, 0, kCursorWords * sizeof(uint32_t), ctx->stream);
+                if (s0 != 0) e = hipMemsetAsync(cur, 0, kCursorWords * sizeof(uint32_t), ctx->stream);
                 rtd::PersistArgs pa{};
-                pa.cursor = ctx->pcursor; pa.worklist = ctx->worklist; pa.wl_count = ctx->pcursor + kCursorWords;
+                pa.cursor = cur; pa.worklist = ctx->worklist; pa.wl_count = cur + kCursorWords; pa.direct = direct ? 1u : 0u;
                 pa.npix_pad = ctx->npix_pad; pa.sample0 = s0; pa.nsamples = ns; pa.threshold = ctx->persist_threshold; pa.rmin = ctx->persist_rmin; pa.chunk = ctx->persist_chunk;
                 pa.nthreads = (uint32_t)ctx->num_cus * 1024u; pa.stack = ctx->pstack;
                 pa.phit = ctx->phit;
@@ -652,7 +677,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                     // 0.28 against 0.22 ms, 256^2 spp 64: 0.35 against 0.32, 1080p spp 4: 0.47 against 0.50, spp 16: 1.29 against
                     // 1.65; the reference's own 1024^2 1-spp frame: 0.20 against 0.14.  The worklist length lives on the device;
                     // the pixel count bounds it.  (RT_KERNEL_PATHS asks for k_paths whatever the size.)
-                    const bool big = !ctx->paths_by_size || (uint64_t)ctx->npix_pad * ns >= (6ull << 20);
+                    const bool big = !ctx->paths_by_size || (uint64_t)ctx->npix_pad * ns >= kPathsCrossover;
                     if (ctx->persist_version == 4 && cache && f.lr_zero != 0 && f.logr == 8) {
                         ctx->last_path_kernel = RT_KERNEL_SEQ;
                         e = rtd::launch_seq(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->seq_nc, ctx->num_cus, ctx->stream);
@@ -665,9 +690,9 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                     if (ctx->last_path_kernel == RT_KERNEL_PERSISTENT)
                         e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, 1, ctx->num_cus, ctx->stream);
                 }
-                if (e == hipSuccess) {
+                if (e == hipSuccess && !direct) {
                     LaunchTimer t(ctx, 1);
-                    e = rtd::launch_accumulate_paths(f, planes_of(ctx), ctx->ppl, ctx->worklist, ctx->pcursor + kCursorWords, ctx->npix_pad, ns,
+                    e = rtd::launch_accumulate_paths(f, planes_of(ctx), ctx->ppl, ctx->worklist, cur + kCursorWords, ctx->npix_pad, ns,
                                                      s0 == 0, s0 + B >= spp, cache, ctx->pacc, ctx->stream);
                 }
             }

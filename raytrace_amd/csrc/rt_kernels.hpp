@@ -52,6 +52,8 @@ struct PrimaryArgs {
                                 // face id << 28 | gl_WorkGroupID.y * 8 << 14 | gl_WorkGroupID.x * 8 (the noise_offset terms, raytrace.comp:304)
     uint32_t* worklist;         // local pixel ids that need shadow/diffuse rays
     uint32_t* wl_count;         // zero before launch
+    uint32_t* zero_words;       // k_primary2: words the prepass clears for the NEXT frame (its cursor set, idle during this one), or null
+    uint32_t zero_count;
     float4* acc;                // (unused by the prepass since it stores the lighting of the pixels it finishes itself)
     DevCounters* counters;
 };
@@ -69,6 +71,8 @@ struct PersistArgs {
     uint32_t rmin;              // k_seq: contexts waiting for their diffuse ray that trigger the in-loop re-arm block
     uint32_t chunk;             // paths per cursor atomic; 0 = the default (128)
     uint32_t nthreads;          // grid size in threads (stride of the albedo stack)
+    uint32_t direct;            // 1: the frame has ONE sample, so a path's light is its pixel's: the kernel stores the lighting planes
+                                // itself (0 + light, / spp / 16: what k_accumulate_paths would do) and writes no light record
     uint32_t* stack;            // [2][(depth-1)][nthreads] packed material of surface j+1 (only touched when depth >= 2; k_persist uses half)
     const float4* phit;         // CACHE: the primary prepass' record per worklist slot (PrimaryArgs::phit): one load per new path
     const float4* sun_lut;      // [2*65536] per-frame shadow-ray table: direction, 1/|direction|
@@ -89,6 +93,7 @@ hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, con
                           int version /* 1 = k_persist */, int nworkgroups, hipStream_t st);
 
 // k_paths (rt_paths.hip): cached-primary frames with lr = 0 and region 256 only
+bool launch_paths_direct_ok(const Frame& f);   // does k_paths honour PersistArgs::direct for this frame?
 hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nworkgroups,
                         hipStream_t st);
 

@@ -276,6 +276,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         const bool hit = cont && kind == 0u;
         const float4 skyv = a.dif_lut[air ? 4u * Pent + 3u : 0u];   // :331-332 / :343-345, tabulated per frame; Pent = the entry F walked
         const uint32_t matv = sc.mat[(hit && !(!LRZ && ps_border(Fvox))) ? Fvox : 0u];   // the hit texel is the texel of the last fetch (:150-154); border: 0
+        // one sample per pixel (a.direct): the ending path's pixel, to store its lighting here (Pitem is its worklist slot then)
+        // (depth <= 4 builds only — the reference's frames are depth 2; launch_paths_direct_ok tells the host)
+        uint32_t lp_done = 0;
+        if (STK == 0 && a.direct) lp_done = a.worklist[fin ? Pitem : 0u];
         const float4 ph = a.phit[nw];       // the prepass' record of the new path's pixel: one 16-byte load
         const uint32_t info = u_bits(ph.w);
         const float ox = ph.x, oy = ph.y, oz = ph.z;
@@ -318,6 +322,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
                 L = vadd(acc, light2);
             }
             const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
+            if (STK == 0 && a.direct) {   // the sum over the pixel's one sample is 0 + light, and the pixel is finished (k_accumulate_paths' arithmetic)
+                const PixelId dp = pixel_of_local(f, lp_done);
+                if (dp.inside) store_lighting(pl, dp.out_index, v3(0.0f + light.x, 0.0f + light.y, 0.0f + light.z), f.spp);
+            } else
 #ifndef RT_DIAG_NO_PL_STORE   // diagnostic build (tools/variant.sh nopl rt_paths.hip -DRT_DIAG_NO_PL_STORE): wrong frames, timing only
             a.pl[Pitem] = PathLight{light.x, light.y, light.z};   // k_accumulate_paths adds a pixel's samples in order
 #else
@@ -519,6 +527,9 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         }
     }
 }
+
+// PersistArgs::direct is honoured by the depth <= 4, region-256 instantiations only (STK = 0)
+bool launch_paths_direct_ok(const Frame& f) { return f.depth <= 4 && f.logr == 8; }
 
 hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nworkgroups,
                         hipStream_t st) {

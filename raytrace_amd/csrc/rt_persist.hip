@@ -140,6 +140,10 @@ __global__ __launch_bounds__(1024) void k_primary2(Scene sc, Frame f, Planes pl,
     __shared__ uint32_t s_coarse[kCoarseWords];
     __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];
     __shared__ uint32_t s_cnt[16], s_off[17];   // worklist append: pixels queued by each wave this round, their slot offsets
+    // the cursor set of the NEXT frame (path cursors + worklist count; idle during this frame) is cleared here instead of by a
+    // memset of its own in front of every frame (two fill kernels, 9 us of a 230 us frame at 1024^2)
+    if (a.zero_words != nullptr && blockIdx.x == 0u)
+        for (uint32_t i = threadIdx.x; i < a.zero_count; i += 1024u) a.zero_words[i] = 0u;
     {
         const uint4* src = reinterpret_cast<const uint4*>(sc.coarse);
         uint4* dst = reinterpret_cast<uint4*>(s_coarse);
@@ -448,7 +452,12 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
                 }
             }
             if (path_done) {   // the path's light; k_accumulate_paths adds the samples of a pixel in order
-                a.pl[item] = PathLight{light.x, light.y, light.z};
+                if (a.direct) {   // one sample per pixel: the sum is 0 + light and the pixel is finished (k_accumulate_paths' arithmetic)
+                    const PixelId dp = pixel_of_local(f, CACHE ? a.worklist[lp] : lp);   // (lp: worklist slot with cached primaries)
+                    if (dp.inside) store_lighting(pl, dp.out_index, v3(0.0f + light.x, 0.0f + light.y, 0.0f + light.z), f.spp);
+                } else {
+                    a.pl[item] = PathLight{light.x, light.y, light.z};
+                }
                 phase = PH_EMPTY;
             }
         }
