@@ -1,6 +1,6 @@
 #!/bin/bash
 # One bench.py line per BASELINE.json config on one GPU (C2, C3, C4, C5); the lines land in gpurun_out/bench_configs.jsonl
-mkdir -p gpurun_out; out=gpurun_out/bench_configs.jsonl; : > $out
+mkdir -p gpurun_out; out=gpurun_out/r3_bench_configs.jsonl; : > $out
 run() { echo "# $*" >> $out; timeout -k 10 500 python bench.py "$@" 2>/dev/null | grep "^{" >> $out; tail -1 $out | cut -c1-220; }
 run --spp 1 --depth 0 --steps 50 --warmup 5 --no-cpu-baseline                                                   # C2: primary rays only
 run --steps 10 --warmup 2                                                                                       # C3: headline
