@@ -397,9 +397,6 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PERSIST_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= 4096) c->persist_chunk = (uint32_t)v & ~63u; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
-    if (c->persist_threshold == 0)   // measured optima.  k_paths (lanes with a parked context, three steps between looks), round 3 after the
-                                     // mask rework, same box: 24 4.28 ms per headline launch, 28 4.22, 32 4.17, 36 4.06-4.15, 40 4.08-4.14, 44 4.12, 48 4.27
-        c->persist_threshold = c->persist_version == 1 ? 32u : 36u;
     if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 16u;   // k_seq: waiting contexts that trigger the re-arm block
     if (c->kernel == RT_KERNEL_PERSISTENT) {
         RT_HIP_CREATE(dev_alloc(c, &c->pcursor, 2 * kCursorSetWords));   // two sets of 8 cursor lines + the worklist count
@@ -678,6 +675,14 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                     // 1.65; the reference's own 1024^2 1-spp frame: 0.20 against 0.14.  The worklist length lives on the device;
                     // the pixel count bounds it.  (RT_KERNEL_PATHS asks for k_paths whatever the size.)
                     const bool big = !ctx->paths_by_size || (uint64_t)ctx->npix_pad * ns >= kPathsCrossover;
+                    // parked lanes that trigger a pass (RT_PERSIST_THRESHOLD overrides): measured optima per kernel.  k_persist 32,
+                    // k_seq 36.  k_paths (lanes with a parked context, three steps between looks), round 3, same box: 24 4.28 ms per
+                    // headline launch, 28 4.22, 32 4.17, 36 4.06-4.15, 40 4.08-4.14, 44 4.12, 48 4.27; deeper frames at region 256 (depth
+                    // 5..8: longer paths, fewer new ones per pass) like 40 — 3840x2160 spp 256 depth 8 launch 51.2 ms at 28, 50.7 at 32, 50.0
+                    // at 36, 49.6 at 40 and 44 —, the 1024^3 frame stays at 36 (20.74 against 20.86 at 40, 21.2 at 44)
+                    const bool to_paths = ctx->persist_version == 3 && cache && big;
+                    if (ctx->persist_threshold == 0)
+                        pa.threshold = ctx->persist_version == 4 ? 36u : (!to_paths ? 32u : ((ctx->cfg.depth > 4 && ctx->region == 256) ? 40u : 36u));
                     if (ctx->persist_version == 4 && cache && f.lr_zero != 0 && f.logr == 8) {
                         ctx->last_path_kernel = RT_KERNEL_SEQ;
                         e = rtd::launch_seq(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->seq_nc, ctx->num_cus, ctx->stream);
