@@ -382,14 +382,17 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray never runs
         bool runS = start && !((Pst & PP_SNAN) || !ok), runF = start && !((Pst & PP_FNAN) || !ok);
         const uint32_t nk0 = (uint32_t)RT_TRACE_LIMIT | ((COUNT && !ok) ? kFreshInvalid : 0u);
-        // (lr = 0 builds step with the q of in-region positions; a level whose origin lies outside takes its first step apart)
-        const bool outside = LRZ && start && ok && (sfx + half < 0.0f || sfy + half < 0.0f || sfz + half < 0.0f);
+        // a level whose origin lies outside the region (rare: a camera outside, a hit on the region's face).  lr = 0 builds step with
+        // the q of positions at or above -R/2, so an origin below takes its first step apart; and a ray that will never move from out
+        // there must not be taken for one that left the region (the pass reads "reached the sky" off the position): see below
+        const bool outside = start && ok && pr_outside<LOGR, LRZ>(sfx, sfy, sfz, f.lr[0], f.lr[1], f.lr[2]);
+        const bool below = LRZ && outside && (sfx + half < 0.0f || sfy + half < 0.0f || sfz + half < 0.0f);
 
         // the two fresh rays as they enter the step loop
         float Spx = sfx, Spy = sfy, Spz = sfz, Tpx = sfx, Tpy = sfy, Tpz = sfz;
         uint32_t Ssx = tx, Ssy = ty, Ssz = tz, Tsx = tx, Tsy = ty, Tsz = tz, nkS = nk0, nkF = nk0;
         bool Tz = true, Txy = false;     // a ray that ends before its first step reports the z face (:90)
-        if (__builtin_expect(__ballot(outside) != 0ull, 0)) {   // rare: the level's origin lies outside the region
+        if (__builtin_expect(__ballot(below) != 0ull, 0)) {
             PSlot TS, TF;
             TS.px = sfx; TS.py = sfy; TS.pz = sfz; TS.sx = tx; TS.sy = ty; TS.sz = tz; TS.axis = 2u;
             TS.nk = runS ? (uint32_t)RT_TRACE_LIMIT : (K_DEAD | K_END);
@@ -399,13 +402,22 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             TS.lx = getnew ? sl.x : (useB ? SB.lx : SA.lx); TS.ly = getnew ? sl.y : (useB ? SB.ly : SA.ly); TS.lz = getnew ? sl.z : (useB ? SB.lz : SA.lz);
             TF.ndx = newface ? -d2.x : Fdx; TF.ndy = newface ? -d2.y : Fdy; TF.ndz = newface ? -d2.z : Fdz;
             TF.lx = newface ? dl.x : (useB ? FB.lx : FA.lx); TF.ly = newface ? dl.y : (useB ? FB.ly : FA.ly); TF.lz = newface ? dl.z : (useB ? FB.lz : FA.lz);
-            first_step(TS, outside); first_step(TF, outside);
-            if (outside) {   // back from the flag word to the booleans
+            first_step(TS, below); first_step(TF, below);
+            if (below) {   // back from the flag word to the booleans
                 Spx = TS.px; Spy = TS.py; Spz = TS.pz; Ssx = TS.sx; Ssy = TS.sy; Ssz = TS.sz;
                 Tpx = TF.px; Tpy = TF.py; Tpz = TF.pz; Tsx = TF.sx; Tsy = TF.sy; Tsz = TF.sz;
                 if (runS) { runS = ps_running(TS.nk); nkS = TS.nk & 0xFFFFu; }
                 if (runF) { runF = ps_running(TF.nk); nkF = TF.nk & 0xFFFFu; Tz = TF.axis == 2u; Txy = TF.axis == 0u; }
             }
+        }
+        if (__builtin_expect(__ballot(outside) != 0ull, 0)) {
+            // a ray that has not moved from an origin outside the region and will not — it is dead, or it stands on a 0 — is "special"
+            // (Q12: NaN position, material 0), not a sky exit: give it its NaN position now
+            uint32_t st0 = 1u;
+            if (outside) st0 = lookup(tx | ty | tz);
+            const float qnan = __builtin_nanf("");
+            if (outside && (nkS & 0xFFFFu) == (uint32_t)RT_TRACE_LIMIT && !(runS && st0 != 0u)) { Spx = Spy = Spz = qnan; runS = false; }
+            if (outside && (nkF & 0xFFFFu) == (uint32_t)RT_TRACE_LIMIT && !(runF && st0 != 0u)) { Tpx = Tpy = Tpz = qnan; runF = false; }
         }
 
         // ---- write the lane's context back

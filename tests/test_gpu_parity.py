@@ -136,7 +136,8 @@ def test_seed_clamp_and_wrap(procedural_region, blue_noise):
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 64, 1, 2), (96, 72, 4, 0), (100, 60, 5, 3), (128, 128, 8, 4)])
 def test_primary_cache_same_pixels(procedural_region, blue_noise, W, H, spp, depth, prepass, monkeypatch):
     """RT_FLAG_CACHE_PRIMARY traces the seed-independent primary ray once per pixel: identical planes, fewer rays.
-    Both prepass kernels: k_primary2 (default: nibble map in LDS) and k_primary (RT_PRIMARY_V=1: one thread per pixel)."""
+    Both prepass kernels: k_primary2 (default: nibble map in LDS) and k_primary (RT_PRIMARY_V=1: one thread per pixel), with the
+    exact cached-primary counters."""
     monkeypatch.setenv("RT_PRIMARY_V", prepass)
     mats, mine = procedural_region
     u = _uniforms(seed=3)
@@ -147,6 +148,35 @@ def test_primary_cache_same_pixels(procedural_region, blue_noise, W, H, spp, dep
     assert gcn.rays_primary == W * H
     assert gcn.rays_shadow == ccn.rays_shadow and gcn.rays_diffuse == ccn.rays_diffuse
     assert gcn.rays == ccn.rays - (spp - 1) * W * H
+    assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
+
+
+def test_prepass_on_poses_regions_and_windows(blue_noise, procedural_region, region512):
+    """The prepass alone (depth 0: every plane it writes, and its exact counters) for camera poses inside terrain, outside the
+    region (the primary ray's first step takes the generic q), looking at the sky, through a scrolled window (lr != 0) and at
+    region 512, against the oracle."""
+    cases = [(256, (0, 0, 0), (-30.0, -128.0, 100.0), np.pi / 2, 0.0), (256, (0, 0, 0), (-30.0, -200.0, 60.0), np.pi / 2, -0.1),
+             (256, (0, 0, 0), (10.0, 10.0, -100.0), 0.3, 0.2), (256, (0, 0, 0), (300.0, 40.0, 140.0), np.pi, -0.4),
+             (256, (48, 0, 32), (18.0, -128.0, 132.0), np.pi / 2, 0.0), (256, (-32, 64, -16), (-62.0, 20.0, 70.0), -0.7, -0.3),
+             (512, (0, 0, 0), (-60.0, -256.0, 110.0), np.pi / 2, -0.05)]
+    for region, lr, origin, heading, pitch in cases:
+        if region == 512:
+            mats, mine = region512
+        elif lr == (0, 0, 0):
+            mats, mine = procedural_region
+        else:
+            mats, mine = world.toroidal_region(lr)
+        u = _uniforms(origin=origin, heading=heading, pitch=pitch, sun=0.2, seed=5, lr=lr)
+        W, H = 104, 72
+        cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, 1, 0, region=region)
+        cfg = render.make_config(W, H, spp=1, depth=0, flags=abi.RT_FLAG_COUNTERS | abi.RT_FLAG_CACHE_PRIMARY, region=region)
+        with render.Context(cfg) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(u)
+            ctx.sync()
+            gpu, gcn = ctx.readback_all(), ctx.counters()
+        _compare(gpu, cpu, gcn, ccn)
 
 
 @pytest.mark.parametrize("kernel", PATH_KERNELS)
@@ -1042,3 +1072,24 @@ def test_seq_kernel_with_two_and_three_paths_per_lane(procedural_region, blue_no
                                flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS)
         _compare(gpu, cpu)
         assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
+
+
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PATHS, abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_SEQ])
+@pytest.mark.parametrize("origin,special", [((-200.0, 10.0, 30.0), True), ((-200.0, 10.0, 124.0), False), ((60.0, 300.0, 20.0), True)])
+def test_cameras_outside_the_region(procedural_region, blue_noise, kernel, origin, special):
+    """The region texture wraps (mod(p + 128, 256), raytrace.comp:137), so a camera outside it fetches the texel on the far side:
+    under the terrain there, every primary ray is a fresh ray on a 0 — "special" (Q12: a non-air hit at a NaN position, whose
+    level rays are dead) —, above it the ray takes one step and leaves.  k_paths reads "reached the sky" off a ray's position,
+    and a ray that never moved from out there must not pass for one that left (the prepass analogue of this was found by the
+    fuzz cases): planes and exact counters against the oracle."""
+    mats, mine = procedural_region
+    u = _uniforms(origin=origin, heading=0.0, pitch=-0.1, sun=0.3, seed=13)
+    W, H, spp, depth = 96, 64, 3, 3
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    assert bool(np.isnan(cpu["depth_f32"]).all()) == special
+    cached = _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
+    for flags in (abi.RT_FLAG_CACHE_PRIMARY, abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS):
+        gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, kernel, flags=flags)
+        _compare(gpu, cpu)
+        if flags & abi.RT_FLAG_COUNTERS:
+            assert gcn.as_dict() == cached
