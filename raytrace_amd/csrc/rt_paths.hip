@@ -1,8 +1,8 @@
-// rt_paths.hip — k_paths, the path kernel RT_KERNEL_DEFAULT runs for cached-primary frames (launches of 6 M paths and more).
+// rt_paths.hip — k_paths, the path kernel RT_KERNEL_DEFAULT runs for cached-primary frames (launches of 3 M pixel-samples and more).
 //
 // Same work, same values as k_persist (rt_persist.hip); what differs is how much of it a wave keeps in flight and how the
-// instructions are spent (measured on gfx950, DESIGN.md 5: the step loop is bound by VALU issue — tools/ubench/valu_rate.hip —
-// the transition passes by memory latency):
+// instructions are spent (measured on gfx950, DESIGN.md 5: VALU issue — tools/ubench/valu_rate.hip —, the vector-memory path's
+// address and tag work, and the latency chains of the transition passes share the bound):
 //   * a lane carries TWO paths (contexts A and B), each with the level's shadow ray and diffuse ray in their own ray slots:
 //     four independent fetch chains per lane instead of two.  k_persist ran at an LDS-pinned four waves per SIMD with 75 of
 //     its 128 VGPRs and its waves parked at s_waitcnt half of their life (round-1 counters); the idle registers now hold
@@ -14,9 +14,12 @@
 //     are gone.
 //   * the swizzle-table words of a slot's next texel are consumed at the top of the NEXT iteration (the slot keeps the
 //     three words, not their OR), so that LDS latency is off the critical path too.
-//   * a ray's bookkeeping word counts DOWN from the loop limit, so "in flight and below the limit" is one compare; a ray that
-//     stops without reaching the sky is only marked ENDED — whether that was a hit, the loop limit or a fresh ray on a 0 is
-//     read off the word (and, for the limit, one more lookup) when the transition pass consumes it.
+//   * (round 3) what the loop needs to know about a ray besides its numbers — in flight?  last step along z?  tx < ty? — are wave
+//     masks in SGPR pairs merged with scalar instructions (rt_pslot.hpp, p_step), not flag bits that cost every slot and step a
+//     subtract, two compares, an OR and three selects; the position update and the iteration count run under the movers' EXEC
+//     mask; the counter only counts — the loop limit is tested in a separate small loop the wave enters when a ray in flight
+//     comes within reach of it (see near_limit); whether an ended ray reached the sky, hit, met the limit or never moved is read
+//     off its position and counter when the transition pass consumes it.  Step group 535 -> 468 VALU, launch 4.31 -> 4.06 ms.
 //   * the shadow slots sit out one repetition in three of the step group (a level's shadow ray is the shorter one) — see
 //     RT_PATHS_SHADOW_REPS.
 // Transitions work as in k_persist (parked lanes, __ballot threshold, per-XCD chunked cursors, direction tables), but a wave in
@@ -30,6 +33,10 @@
 // four slots' accesses batched); nibble map and byte array biased by one so that "mixed or not" needs
 // no compare (2.5 % fewer loop instructions, 1 % slower: ended slots then keep fetching their byte); positions scaled by four
 // to share the table-index multiply (6 % fewer instructions, 1.7 % slower: more packed-math issue slots).
+// Round 3, same way (profiles/r3_kpaths_variants_*.txt): selects forced into SGPR-pair form, selects instead of the EXEC-masked
+// update, byte loads skipped by a branch when no lane needs one (+5 %), 1 / |direction| computed instead of loaded (+3 %), one byte
+// load per pair of rays (+9 %), a wave's new paths from one pixel (+5.5 %) — all lost; per-lane `bool`s carried round the loop
+// (the compiler makes 0/1 registers of them: 550 VALU per group) lost to explicit 64-bit masks.
 //
 // Restrictions (rt_api.hip dispatches everything else to k_persist): RT_FLAG_CACHE_PRIMARY.  Scrolled regions (lr != 0, terrain
 // streaming) run the LRZ = false instantiations: generic q, lr in the sky test, the shader's own mod for the texel and its border
