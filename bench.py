@@ -58,6 +58,9 @@ def parse_args():
                          "travelled; region 256 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the additional 3840x2160 spp=256 depth=8 measurement")
+    ap.add_argument("--share-of", default=None, metavar="r/N",
+                    help="diagnostic, N = 1 only: render rank r's tiles of an N-rank run on this one GPU (tools/scale_emulation.py); "
+                         "the line's value then counts that share's rays only and config.share_of says so")
     return ap.parse_args()
 
 
@@ -119,6 +122,13 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
+    share_rank = share_world = 0
+    if args.share_of:
+        if world != 1:
+            sys.exit("bench.py --share-of is a one-GPU diagnostic")
+        share_rank, share_world = (int(x) for x in args.share_of.split("/"))
+        if not 0 <= share_rank < share_world:
+            sys.exit("bench.py --share-of r/N needs 0 <= r < N")
 
     import torch
     import torch.distributed as dist
@@ -199,7 +209,7 @@ def main():
         rank's record (elapsed, launch timings, exact counts), the whole-job figures and rank 0's frame hash."""
 
         def make_ctx(flags, depth=D):
-            cfg = render.make_config(W, H, spp=SPP, depth=depth, device=local_rank, tile_rank=rank, tile_world=world,
+            cfg = render.make_config(W, H, spp=SPP, depth=depth, device=local_rank, tile_rank=share_rank if share_world else rank, tile_world=share_world or world,
                                      kernel=kernel, flags=flags | xflags, region=REGION)
             ctx = render.Context(cfg)
             ctx.upload_world(mats, mine)
@@ -377,7 +387,7 @@ def main():
             "config": {"workload": "%dx%d spp=%d depth=%d, procedural %d^3 region seed 0x5EED, pose (%g,%g,%g) h=pi/2 p=0 sun=0"
                                    % ((W, H, SPP, D, REGION) + tuple(pose["origin"])), "kernel": rec["kernel"],
                        "rays_per_frame": int(rec["rays_total"]), "reference_equivalent_rays_per_frame": int(rec["ref_rays_total"]),
-                       "algorithmic_bytes_per_frame": int(rec["balg_total"]), "parallelism": "tiles%d" % world,
+                       "algorithmic_bytes_per_frame": int(rec["balg_total"]), "parallelism": "tiles%d" % world, **({"share_of": args.share_of} if args.share_of else {}),
                        "primary_cache": bool(args.cache_primary), "lr": list(LR), "frame_sha256_16": rec["sha"],
                        "seed": args.seed + ((args.steps + args.warmup - 1) if args.vary_seed else 0),
                        "gather": None if not dist_on else (("rt_gather_gbuffer over RCCL, " + ("overlapped with the next frame" if overlap

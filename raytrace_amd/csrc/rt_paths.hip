@@ -61,6 +61,9 @@
 #ifndef RT_PATHS_STEPS_PER_CHECK
 #define RT_PATHS_STEPS_PER_CHECK 3
 #endif
+#ifndef RT_PATHS_DRAIN_PARK
+#define RT_PATHS_DRAIN_PARK 8   // parked lanes that run the pass of a wave whose paths have run out (1, 2, 4, 8, 16 measured: r3_drain_park_threshold.txt)
+#endif
 #ifndef RT_PATHS_SHADOW_REPS
 #define RT_PATHS_SHADOW_REPS 0x3
 #endif
@@ -505,9 +508,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             uint64_t idleA = 0ull, idleB = 0ull;   // lanes whose context is empty for good (no paths left)
             if (exhausted) { idleA = __ballot((PA.st >> 20) == 0u); idleB = __ballot((PB.st >> 20) == 0u); }
             park = (eA & ~idleA) | (eB & ~idleB);
-            // (once the paths have run out nobody refills the wave: two parked lanes are then enough — 0.7 %; a wave spends the last
-            // 4 % of its life in that state and the kernel's last 4 % waiting for its slowest waves: RT_DIAG_WAVE_TIMES)
-            if ((uint32_t)__popcll(park) >= (exhausted ? 2u : threshold) || (eA & eB) == ~0ull) break;
+            // (once the paths have run out nobody refills the wave, and fewer parked lanes are enough.  From there a wave makes 24 more
+            // looks and 22 passes on the headline frame — 0.21 ms, whatever the launch's size; the slowest waves twice that:
+            // tools/drain_times.py, profiles/r3_drain_*.txt, DESIGN.md 5 "The drain")
+            if ((uint32_t)__popcll(park) >= (exhausted ? (uint32_t)RT_PATHS_DRAIN_PARK : threshold) || (eA & eB) == ~0ull) break;
             if (COUNT) { d_iters++; d_live += (uint32_t)__popcll(~eA) + (uint32_t)__popcll(~eB); }
             if (__builtin_expect((looks++ & 15u) == 0u, 0)) {
                 while (__builtin_expect(near_limit() != 0ull, 0)) step_all(std::true_type{}, std::true_type{});
@@ -536,12 +540,18 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         wave_add(&cn->hits, c_hits); wave_add(&cn->material_fetches, c_hits); wave_add(&cn->sky_exits, c_sky);
         wave_add(&cn->limit_exits, c_limit); wave_add(&cn->border_fetches, c_border); wave_add(&cn->noise_fetches, c_noise);
         if (lane == 0) {
+#ifndef RT_DIAG_WAVE_TIMES
             atomicAdd(&cn->dbg_loop_iters, d_iters); atomicAdd(&cn->dbg_f_lanes, d_live);
             atomicAdd(&cn->dbg_passes, d_passf); atomicAdd(&cn->dbg_pass_lanes, d_plf);
-#ifdef RT_DIAG_WAVE_TIMES
+#else       // wave lifetimes on the 100 MHz clock (tools/drain_times.py reads them from RT_DEBUG_STATS' raw lines)
+            (void)d_iters; (void)d_live; (void)d_passf; (void)d_plf;
             const unsigned long long t1 = wall_clock64();
             atomicAdd(&cn->dbg_s_execs, t1 - t_wave0); atomicMax(&cn->dbg_f_execs, t1); atomicMax(&cn->dbg_sky_lanes, ~t_wave0);
             atomicAdd(&cn->dbg_s_lanes, t_exh ? t1 - t_exh : 0ull);
+            atomicMax(&cn->dbg_loop_iters, t_exh ? ~t_exh : 0ull);    // earliest moment a wave found the paths handed out
+            atomicAdd(&cn->dbg_passes, 1ull);                          // waves
+            atomicAdd(&cn->dbg_pass_lanes, t1 & 0xFFFFFFFFFFull);      // sum of the end times (40 bits each)
+            atomicAdd(&cn->dbg_f_lanes, (t_exh ? t_exh : t1) & 0xFFFFFFFFFFull);   // sum of the exhaustion times
 #endif
         }
     }
