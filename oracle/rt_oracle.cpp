@@ -17,7 +17,9 @@
  * generation smoke test: src/util.rs:417-435,496-505,585-603; src/world/chunk_storage.rs:154-183),
  * and the reference itself (Rust + Vulkan + glslc) cannot be built or run in this image.
  * This restatement is pinned only by known-answer tests derived by hand from the shader text
- * (tests/test_oracle_kat.py).
+ * (tests/test_oracle_kat.py) and by agreeing — trace_ray and the primary planes bit for
+ * bit — with a second restatement written from the GLSL alone (tests/shader_trace.py, tests/shader_formulas.py:
+ * K10-K14).  Neither is the reference's own output.
  *
  * Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp).
  */
