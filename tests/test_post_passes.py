@@ -93,6 +93,42 @@ def test_finalize_known_values(blue_noise):
     assert abs(int(out2[h - 1 - y, x, 2]) - int(np.floor((t + n[y, x, 0] / 255 / 128) * 255 + 0.5))) <= 1
 
 
+def test_post_passes_of_a_terrain_frame_against_the_second_restatement(procedural_region, blue_noise):
+    """The oracle's six denoise dispatches and its finalize against tests/shader_post.py (float64, written from the two shaders):
+    a rendered terrain frame (sky, terrain, silhouettes) and random planes; both descriptor bindings.  The restatement keeps
+    real numbers where the shader stores UNORM texels, so a stored texel may differ from it by the rounding (0.5) plus what fp32
+    arithmetic and, for the denoise, five intermediate quantisations add: 3 of 65535 per channel, 0.52 of 255 for finalize —
+    a wrong weight, offset, binding or curve segment is off by hundreds."""
+    from tests import shader_post as sp
+    from raytrace_amd import world as rt_world
+    mats, mine = procedural_region
+    W, H = 72, 48
+    u = po.camera_uniforms((-30.0, -128.0, 100.0), np.pi / 2, -0.05, 0.3, 5)
+    planes, _ = po.render(mats, mine, blue_noise, u, W, H, 1, 2)
+    assert (planes["normal_r8"] == 16).any() and (planes["normal_r8"] < 16).any()
+    cases = [(planes["lighting_rgba16"], planes["depth_r16"], planes["normal_r8"]), _planes(40, 56, seed=3)]
+    for lighting, depth, normal in cases:
+        for faithful in (True, False):
+            got = po.denoise(lighting, depth, normal, faithful).astype(np.int64)
+            want = sp.denoise(lighting, depth, normal, faithful).astype(np.int64)
+            assert np.abs(got - want).max() <= 3, (faithful, np.abs(got - want).max())
+            assert (got[..., 3] == want[..., 3]).all()
+        # one dispatch on its own, real-valued: the stored texel is the rounding of it
+        for size, swapped in ((1, False), (2, True), (16, True)):
+            d, n = depth.astype(np.int64), normal.astype(np.int64)
+            real, _ = sp.denoise_pass(lighting, n if swapped else d, d if swapped else n, size)
+            assert np.isfinite(real).all()
+    # the faithful chain differs from the fixed one (the quirk is observable on this frame)
+    assert (po.denoise(*cases[0], True) != po.denoise(*cases[0], False)).any()
+    den = po.denoise(planes["lighting_rgba16"], planes["depth_r16"], planes["normal_r8"], True)
+    out = po.finalize(planes["albedo_rgba8"], planes["emission_rgba8"], planes["fog_rgba8"], den, planes["depth_r16"], blue_noise)
+    real = sp.finalize(planes["albedo_rgba8"], planes["emission_rgba8"], planes["fog_rgba8"], den, planes["depth_r16"], blue_noise)
+    got_rgb = out[..., [2, 1, 0]].astype(np.float64)          # memory order B, G, R, A
+    assert np.abs(got_rgb - real).max() <= 0.52, np.abs(got_rgb - real).max()
+    assert (out[..., 3] == 255).all()
+    assert len(np.unique(out[..., :3])) > 50                   # a real picture: sky gradient, lit and fogged terrain
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("faithful", [True, False])
 @pytest.mark.parametrize("W,H,spp", [(96, 64, 1), (200, 120, 4)])
