@@ -108,7 +108,7 @@ typedef enum RtKernel {
 #define RT_FLAG_COUNTERS      0x1u  /* count rays/iterations/hits exactly (slower; for B_alg + parity)   */
 #define RT_FLAG_CACHE_PRIMARY 0x2u  /* spp>1: trace the (seed-independent) primary ray once per pixel    */
 #define RT_FLAG_TIMING        0x4u  /* bracket the traversal-kernel launches with HIP events (RtTiming.trace_ms)  */
-#define RT_FLAG_TIMING_ALL    0xCu  /* ... and every other launch as well (RtTiming.shade_ms); includes RT_FLAG_TIMING */
+#define RT_FLAG_TIMING_ALL    0xCu  /* ... and every other launch and the frame as well (shade_ms, frame_ms); includes RT_FLAG_TIMING */
 #define RT_FLAG_TRUSTED_WORLD 0x10u /* rt_upload_slice: the host vouches that every minefield value is <= 30 (the reference
                                        writes 0..6); the slab is applied without the host-side scan of its bytes        */
 
@@ -174,8 +174,10 @@ typedef struct RtCounters {
     uint64_t frames;
 } RtCounters;
 
-/* HIP-event timings, milliseconds.  frame_ms = the last rt_draw_frame; the per-launch sums (RT_FLAG_TIMING: trace_ms,
- * RT_FLAG_TIMING_ALL: shade_ms too) cover every frame drawn since the previous rt_get_timing call. */
+/* HIP-event timings, milliseconds, of a context created with a timing flag (all zero without: an event between two launches is
+ * 4-5 us of GPU idle time).  RT_FLAG_TIMING: trace_ms / trace_launches.  RT_FLAG_TIMING_ALL: shade_ms / other_launches and
+ * frame_ms (the last rt_draw_frame, first launch to last) too.  The per-launch sums cover every frame drawn since the previous
+ * rt_get_timing call. */
 typedef struct RtTiming {
     float    frame_ms;        /* whole frame on the context's stream                      */
     float    trace_ms;        /* sum of traversal-kernel launches                         */

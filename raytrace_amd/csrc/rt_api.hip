@@ -615,7 +615,10 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const rtd::Frame f = frame_of(ctx, u);
     const bool count = (ctx->cfg.flags & RT_FLAG_COUNTERS) != 0;
-    RT_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
+    // frame_ms of rt_get_timing: two events per frame, recorded only for a context that asked for every timing — an event between
+    // the last kernel of one frame and the first of the next is 4-5 us during which the GPU idles (profiles/r3_frame_timeline.txt)
+    const bool frame_events = (ctx->cfg.flags & RT_FLAG_TIMING_ALL) == RT_FLAG_TIMING_ALL;
+    if (frame_events) RT_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
     int rc = RT_OK;
     if (ctx->kernel == RT_KERNEL_MEGA) {
         LaunchTimer t(ctx, 0);
@@ -707,7 +710,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
     } else {
         rc = draw_wavefront(ctx, f);
     }
-    RT_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+    if (frame_events) RT_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
     ctx->frame_recorded = true;
     if (count) { ctx->host_noise_base += (uint64_t)ctx->cfg.spp; ctx->host_frames++; }
     return rc;
@@ -1073,7 +1076,8 @@ int rt_get_timing(RtContext* ctx, RtTiming* out) {
     if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_get_timing: no frame drawn yet");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RT_HIP(ctx, hipEventElapsedTime(&out->frame_ms, ctx->ev_frame0, ctx->ev_frame1));
+    if ((ctx->cfg.flags & RT_FLAG_TIMING_ALL) == RT_FLAG_TIMING_ALL)   // 0 for a context created without RT_FLAG_TIMING_ALL
+        RT_HIP(ctx, hipEventElapsedTime(&out->frame_ms, ctx->ev_frame0, ctx->ev_frame1));
     // per-launch events accumulate over every frame drawn since the previous rt_get_timing (no per-frame sync needed)
     for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
         float ms = 0.0f;

@@ -365,7 +365,15 @@ def test_errors_are_reported_not_fatal(procedural_region, blue_noise):
         ctx.upload_noise(blue_noise)
         ctx.draw_frame(_uniforms())
         ctx.sync()
-        assert ctx.timing().frame_ms > 0
+        assert ctx.timing().frame_ms == 0          # events are recorded for contexts that ask for timings only
+    for flags, frame in ((abi.RT_FLAG_TIMING, False), (abi.RT_FLAG_TIMING_ALL, True)):
+        with render.Context(render.make_config(32, 32, flags=flags)) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(_uniforms())
+            ctx.sync()
+            t = ctx.timing()
+            assert t.trace_ms > 0 and t.trace_launches >= 1 and (t.frame_ms > 0) == frame and (t.other_launches > 0) == frame
 
 
 @pytest.mark.parametrize("W,H,spp,depth", [(1920, 1080, 64, 4)])
