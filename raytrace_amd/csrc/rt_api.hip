@@ -35,6 +35,8 @@ constexpr size_t kCursorSetWords = kCursorWords + 32;
 // RT_KERNEL_DEFAULT: launches of at least this many pixel-samples run on k_paths, smaller ones on k_persist (measured crossover,
 // round 3, same box: 1080p spp 1 (2.1 M) 0.351 against 0.348 ms per frame, spp 2 (4.1 M) 0.409 against 0.442; 1024^2 spp 1 0.252 against 0.229)
 constexpr uint64_t kPathsCrossover = 3ull << 20;
+// light records of one launch above which k_paths streams them out and k_accumulate_paths streams them in (see rt_draw_frame)
+constexpr uint64_t kStreamRecordBytes = 384ull << 20;
 
 struct RtContext {
     RtConfig cfg{};
@@ -97,6 +99,7 @@ struct RtContext {
     float4* pacc = nullptr;
     rtd::PathLight* ppl = nullptr;
     uint32_t persist_batch = 1;
+    int pl_stream_mode = -1;      // RT_PL_STREAM: -1 = by size (kStreamRecordBytes); bit 0 streaming stores, bit 1 streaming loads
     uint32_t persist_chunk = 0;   // RT_PERSIST_CHUNK: paths per cursor atomic (multiple of 64); 0 = automatic
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
     int persist_version = 1;      // 1 = k_persist, 3 = k_paths (RT_KERNEL_PATHS), 4 = k_seq (RT_KERNEL_SEQ)
@@ -395,6 +398,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
     if (const char* s = getenv("RT_PRIMARY_V")) { int v = atoi(s); if (v == 1 || v == 2) c->primary_version = v; }
     if (const char* s = getenv("RT_PERSIST_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->persist_threshold = (uint32_t)v; }
+    if (const char* s = getenv("RT_PL_STREAM")) { int v = atoi(s); if (v >= 0 && v <= 3) c->pl_stream_mode = v; }
     if (const char* s = getenv("RT_PERSIST_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= 4096) c->persist_chunk = (uint32_t)v & ~63u; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
     if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 16u;   // k_seq: waiting contexts that trigger the re-arm block
@@ -670,6 +674,14 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 pa.phit = ctx->phit;
                 pa.sun_lut = ctx->sun_lut; pa.dif_lut = ctx->dif_lut;
                 pa.pl = ctx->ppl; pa.counters = ctx->d_counters;
+                // light records of this launch: streamed past the caches when there are more of them than would stay there until the
+                // accumulate launch reads them (the Infinity Cache holds 256 MB; RT_PL_STREAM = 0 / 1 / 2 / 3 forces never / stores /
+                // loads / both)
+                const uint64_t record_bytes = (uint64_t)ctx->npix_pad * ns * sizeof(rtd::PathLight);
+                const bool big_records = record_bytes > kStreamRecordBytes;
+                const bool stream_st = ctx->pl_stream_mode < 0 ? big_records : (ctx->pl_stream_mode & 1) != 0;
+                const bool stream_ld = ctx->pl_stream_mode < 0 ? big_records : (ctx->pl_stream_mode & 2) != 0;
+                pa.pl_stream = stream_st ? 1u : 0u;
                 if (e == hipSuccess) {
                     LaunchTimer t(ctx, 0);
                     // k_paths pays for its two contexts per lane once there is enough work to keep them filled: measured
@@ -701,7 +713,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 if (e == hipSuccess && !direct) {
                     LaunchTimer t(ctx, 1);
                     e = rtd::launch_accumulate_paths(f, planes_of(ctx), ctx->ppl, ctx->worklist, cur + kCursorWords, ctx->npix_pad, ns,
-                                                     s0 == 0, s0 + B >= spp, cache, ctx->pacc, ctx->stream);
+                                                     s0 == 0, s0 + B >= spp, cache, stream_ld, ctx->pacc, ctx->stream);
                 }
             }
         }

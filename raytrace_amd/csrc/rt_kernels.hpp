@@ -73,6 +73,8 @@ struct PersistArgs {
     uint32_t nthreads;          // grid size in threads (stride of the albedo stack)
     uint32_t direct;            // 1: the frame has ONE sample, so a path's light is its pixel's: the kernel stores the lighting planes
                                 // itself (0 + light, / spp / 16: what k_accumulate_paths would do) and writes no light record
+    uint32_t pl_stream;         // k_paths: 1 = the light records go out as streaming (`nt`) stores — set when a launch's records are too many
+                                // to be worth keeping in L2 / the Infinity Cache until k_accumulate_paths reads them
     uint32_t* stack;            // [2][(depth-1)][nthreads] packed material of surface j+1 (only touched when depth >= 2; k_persist uses half)
     const float4* phit;         // CACHE: the primary prepass' record per worklist slot (PrimaryArgs::phit): one load per new path
     const float4* sun_lut;      // [2*65536] per-frame shadow-ray table: direction, 1/|direction|
@@ -82,7 +84,7 @@ struct PersistArgs {
 };
 hipError_t launch_accumulate_paths(const Frame& f, const Planes& planes, const PathLight* pl, const uint32_t* worklist,
                                    const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool last_batch,
-                                   bool cache, float4* acc, hipStream_t st);
+                                   bool cache, bool stream, float4* acc, hipStream_t st);
 hipError_t launch_sphere_lut(float4* lut, hipStream_t st);
 hipError_t launch_dif_lut(const float4* sphere, float4* lut, hipStream_t st);
 hipError_t launch_sun_lut(const Frame& f, float4* lut, hipStream_t st);

@@ -337,7 +337,16 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
                 if (dp.inside) store_lighting(pl, dp.out_index, v3(0.0f + light.x, 0.0f + light.y, 0.0f + light.z), f.spp);
             } else
 #ifndef RT_DIAG_NO_PL_STORE   // diagnostic build (tools/variant.sh nopl rt_paths.hip -DRT_DIAG_NO_PL_STORE): wrong frames, timing only
-            a.pl[Pitem] = PathLight{light.x, light.y, light.z};   // k_accumulate_paths adds a pixel's samples in order
+            {   // k_accumulate_paths adds a pixel's samples in order.  The record is read once, after the launch: when a launch
+                // writes more of them than the caches would keep (PersistArgs::pl_stream; the headline launch writes 1.6 GB) they go
+                // out as streaming stores (`nt`) and do not push the scene out of L2 — headline launch 4.06 -> 4.03 ms, C4 50.0 -> 48.9,
+                // C5 20.85 -> 20.73 (profiles/r3_pl_nontemporal.txt)
+                typedef float f3v __attribute__((ext_vector_type(3)));
+                const f3v val = {light.x, light.y, light.z};
+                PathLight* dst = a.pl + Pitem;
+                if (a.pl_stream) asm volatile("global_store_dwordx3 %0, %1, off nt" :: "v"(dst), "v"(val) : "memory");
+                else asm volatile("global_store_dwordx3 %0, %1, off" :: "v"(dst), "v"(val) : "memory");
+            }
 #else
             if (light.x == 12345.678f) a.pl[Pitem] = PathLight{light.x, light.y, light.z};   // keeps the unwinding alive, never stores
 #endif

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(1024, 4) void k_persist(Scene sc, Frame f, Planes p
 // sample per frame, the sum over frames is the build's spp extension).  The last batch of a frame writes the pixel's
 // lighting planes itself (sum / spp / 16, raytrace.comp:352-356) — the prepass has done that for the pixels it finished —
 // so no separate resolve launch is needed.
-template <bool CACHE>
+template <bool CACHE, bool STREAM>
 __global__ __launch_bounds__(256) void k_accumulate_paths(Frame f, Planes planes, const PathLight* __restrict__ pl,
                                                           const uint32_t* __restrict__ worklist,
                                                           const uint32_t* __restrict__ wl_count, uint32_t npix_pad,
@@ -601,7 +601,11 @@ __global__ __launch_bounds__(256) void k_accumulate_paths(Frame f, Planes planes
     const uint32_t lp = CACHE ? worklist[w] : w;
     float4 v = first_batch ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : acc[lp];
     for (uint32_t b = 0; b < nsamples; b++) {
-        const PathLight l = pl[(size_t)b * nwork + w];
+        // STREAM: read once and too many to have stayed in the caches — streaming loads, like k_paths' stores of them (headline frame
+        // 4.29 -> 4.25 ms with both; a launch whose records fit the Infinity Cache is better off with plain loads)
+        const float* src = &pl[(size_t)b * nwork + w].x;
+        const PathLight l = STREAM ? PathLight{__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1), __builtin_nontemporal_load(src + 2)}
+                                   : pl[(size_t)b * nwork + w];
         v.x = v.x + l.x; v.y = v.y + l.y; v.z = v.z + l.z;
     }
     if (last_batch) {
@@ -614,11 +618,13 @@ __global__ __launch_bounds__(256) void k_accumulate_paths(Frame f, Planes planes
 
 hipError_t launch_accumulate_paths(const Frame& f, const Planes& planes, const PathLight* pl, const uint32_t* worklist,
                                    const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool last_batch,
-                                   bool cache, float4* acc, hipStream_t st) {
+                                   bool cache, bool stream, float4* acc, hipStream_t st) {
     if (npix_pad == 0) return hipSuccess;
     dim3 grid((npix_pad + 255u) / 256u), block(256);
-    if (cache) hipLaunchKernelGGL(k_accumulate_paths<true>, grid, block, 0, st, f, planes, pl, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, last_batch ? 1 : 0, acc);
-    else hipLaunchKernelGGL(k_accumulate_paths<false>, grid, block, 0, st, f, planes, pl, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, last_batch ? 1 : 0, acc);
+#define RT_LAUNCH_ACC(C, S) hipLaunchKernelGGL((k_accumulate_paths<C, S>), grid, block, 0, st, f, planes, pl, worklist, wl_count, npix_pad, nsamples, first_batch ? 1 : 0, last_batch ? 1 : 0, acc)
+    if (cache) { if (stream) RT_LAUNCH_ACC(true, true); else RT_LAUNCH_ACC(true, false); }
+    else { if (stream) RT_LAUNCH_ACC(false, true); else RT_LAUNCH_ACC(false, false); }
+#undef RT_LAUNCH_ACC
     return hipGetLastError();
 }
 
