@@ -853,6 +853,22 @@ def test_scheduling_parameters_do_not_change_results(procedural_region, blue_noi
     assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2", "3"])
+def test_light_records_streamed_or_cached_give_the_same_frame(procedural_region, blue_noise, mode, monkeypatch):
+    """RT_PL_STREAM: k_paths' light records as plain or streaming (`nt`) stores, k_accumulate_paths reading them with plain or
+    streaming loads (the library chooses by the launch's size; a frame of test size never gets there by itself) — a cache policy,
+    not a value: the frame is the oracle's either way, multi-launch accumulation included."""
+    monkeypatch.setenv("RT_PL_STREAM", mode)
+    monkeypatch.setenv("RT_PERSIST_BATCH", "3")
+    mats, mine = procedural_region
+    u = _uniforms(seed=29)
+    W, H, spp, depth = 104, 72, 7, 5
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, abi.RT_KERNEL_PATHS, flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS)
+    _compare(gpu, cpu)
+    assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
+
+
 def test_headline_frame_equals_the_oracle(procedural_region, blue_noise):
     """bench.py's workload in full — 1920x1080, spp 64, depth 4, default pose — against the oracle on every pixel of every
     plane, for both path kernels; counters (349 M rays) for the kernel RT_KERNEL_DEFAULT picks at this size."""
