@@ -31,7 +31,7 @@ import numpy as np  # noqa: E402
 
 COUNTERS_FILE = "r3_counters.json"   # written by tools/pmc_to_json.py on the GPU box (tools/profile_r3.sh)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-KERNEL_NAMES = {"seq": "k_seq", "paths": "k_paths", "persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}
+KERNEL_NAMES = {"paths": "k_paths", "persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}
 
 
 def parse_args():
@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1, help="seed of the frame's first sample (pipeline.rs:201 starts at 1)")
     ap.add_argument("--vary-seed", action="store_true",
                     help="frame i is drawn with seed + i (every step renders a different frame; the hash is the last one's)")
-    ap.add_argument("--kernel", choices=["default", "seq", "paths", "persistent", "wavefront", "mega"], default="default")
+    ap.add_argument("--kernel", choices=["default", "paths", "persistent", "wavefront", "mega"], default="default")
     ap.add_argument("--no-cache-primary", dest="cache_primary", action="store_false",
                     help="re-trace the (seed-independent) primary ray for every sample, like spp reference frames would")
     ap.set_defaults(cache_primary=True)
@@ -57,6 +57,12 @@ def parse_args():
                          "toroidal window around it and the camera moves with it — what every frame looks like once the camera has "
                          "travelled; region 256 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
+                    help="2 (default): RT_FLAG_FRAMES_IN_FLIGHT_2 — the K frames are enqueued back to back and frame k+1 starts on the CUs "
+                         "frame k's draining path kernel leaves; 1: one frame slot (the reference's fence discipline, pipeline.rs:162-172). "
+                         "The line reports both the throughput figure and the latency of ONE frame (draw + wait).")
+    ap.add_argument("--no-reference-frame", action="store_true",
+                    help="N = 1: skip the \"reference_frame\" sub-record (the reference's own frame: 1024x1024, 1 spp, depth 2, + post passes)")
     ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the additional 3840x2160 spp=256 depth=8 measurement")
     ap.add_argument("--share-of", default=None, metavar="r/N",
                     help="diagnostic, N = 1 only: render rank r's tiles of an N-rank run on this one GPU (tools/scale_emulation.py); "
@@ -170,9 +176,11 @@ def main():
         os.environ.setdefault("RT_RESERVE_CUS", "8")
     reserve_cus = int(os.environ.get("RT_RESERVE_CUS", "0") or 0)
 
-    kernel = {"default": abi.RT_KERNEL_DEFAULT, "seq": abi.RT_KERNEL_SEQ, "paths": abi.RT_KERNEL_PATHS, "persistent": abi.RT_KERNEL_PERSISTENT,
+    kernel = {"default": abi.RT_KERNEL_DEFAULT, "paths": abi.RT_KERNEL_PATHS, "persistent": abi.RT_KERNEL_PERSISTENT,
               "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
+    if args.frames_in_flight == 2:
+        xflags |= abi.RT_FLAG_FRAMES_IN_FLIGHT_2
     noise = np.fromfile(os.path.join(ROOT, "tests", "golden", "blue_noise_512.rgba"), dtype=np.uint8)
     REGION = args.region
     LR = tuple(int(v) for v in args.lr.split(","))
@@ -223,7 +231,7 @@ def main():
         cctx.draw_frame(u0)
         cctx.sync()
         # the report names the kernel the frame actually ran on (RT_KERNEL_DEFAULT picks k_paths / k_persist per frame)
-        rec["kernel"] = {abi.RT_KERNEL_SEQ: "seq", abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent",
+        rec["kernel"] = {abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent",
                          abi.RT_KERNEL_WAVEFRONT: "wavefront", abi.RT_KERNEL_MEGA: "mega"}[cctx.kernel_in_use()]
         cn = cctx.counters()
         cctx.destroy()
@@ -232,7 +240,7 @@ def main():
         rec["trace_bytes"] = cn.minefield_fetches + 4 * cn.material_fetches
         rec["balg"] = cn.algorithmic_bytes()
         rec["ref_rays"] = cn.rays + (SPP - 1) * cn.pixels if args.cache_primary else cn.rays
-        if rec["kernel"] in ("seq", "paths", "persistent") and args.cache_primary and D >= 1:
+        if rec["kernel"] in ("paths", "persistent") and args.cache_primary and D >= 1:
             # the dominant kernel walks only shadow/diffuse rays; the primary prepass (k_primary2) is a separate launch,
             # untimed for the roofline: subtract its share, measured with a depth-0 counting frame
             c0 = make_ctx(abi.RT_FLAG_COUNTERS, depth=0)
@@ -246,6 +254,7 @@ def main():
         inf = ctx.info()
         rec["samples_per_launch"], rec["light_record_bytes"], rec["light_budget_bytes"] = inf.samples_per_launch, inf.light_record_bytes, inf.light_record_budget_bytes
         rec["device_bytes"] = inf.device_bytes
+        rec["launches_in_flight"], rec["frames_in_flight"] = inf.launches_in_flight, inf.frames_in_flight
         frames = None
         if dist_on and rank == 0:
             frames = {b: torch.empty(W * H * bpp[b], dtype=torch.uint8, device=dev) for b in gather_ids}
@@ -254,20 +263,21 @@ def main():
         comm = shared["comm"]
         if dist_on and not rccl:
             gbytes = ctx.gbuffer_bytes()
-            local_view = torch.as_tensor(_DevArray(ctx.gbuffer_ptr(), gbytes), device=dev)
             gathered = torch.empty(world * gbytes, dtype=torch.uint8, device=dev) if rank == 0 else None
         torch.cuda.synchronize(dev)
         state = {"frame": 0}
 
-        def step():
-            u = uniforms(args.seed + (state["frame"] if args.vary_seed else 0))
-            state["frame"] += 1
+        def step(fixed=False):
+            u = uniforms(args.seed + (state["frame"] if args.vary_seed and not fixed else 0))
+            if not fixed:
+                state["frame"] += 1
             ctx.draw_frame(u)
             if rccl:
                 ctx.gather_gbuffer(comm, 0, [frames[b].data_ptr() for b in gather_ids] if rank == 0 else None, overlapped=overlap)
             elif dist_on:      # rehearsal backend (gloo): blocks staged through host memory, un-tiled by the library on rank 0
                 ctx.sync()
-                host = local_view.cpu()
+                # (the block of the frame drawn last: with two frame slots the pointer alternates)
+                host = torch.as_tensor(_DevArray(ctx.gbuffer_ptr(), gbytes), device=dev).cpu()
                 if rank == 0:
                     parts = [torch.empty_like(host) for _ in range(world)]
                     dist.gather(host, parts, dst=0)
@@ -291,8 +301,18 @@ def main():
         for _ in range(warmup):
             step()
         fence()
-        if warmup > 0:
-            ctx.timing()      # drop the warm-up frames' launch events
+        # latency of ONE frame — draw, (gather,) wait, nothing else in flight: the reference's per-frame fence (pipeline.rs:162-172).
+        # Before the timed region (so that the last timed frame stays the frame that is hashed), with the first frame's seed.
+        lat = []
+        for _ in range(3 if warmup > 0 else 0):
+            t1 = time.perf_counter()
+            step(fixed=True)
+            ctx.sync()
+            lat.append(time.perf_counter() - t1)
+            fence()
+        rec["latency_ms"] = sorted(lat)[len(lat) // 2] * 1e3 if lat else None
+        ctx.timing()          # drop the warm-up frames' launch events
+        ctx.gather_timing()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -301,6 +321,8 @@ def main():
         # per-launch HIP events of the K timed frames (recorded on the stream the kernels run on; read after the fence)
         tm = ctx.timing()
         rec["trace_ms"], rec["trace_launches"] = tm.trace_ms, tm.trace_launches
+        gt = ctx.gather_timing()
+        rec["gather_ms"], rec["gathers"] = gt
         # content hash of the finished (last) frame on rank 0, outside the timed region: equal for every N
         sha = None
         if rank == 0:
@@ -362,6 +384,59 @@ def main():
                 roofline["valu"] = prof["valu"]
         return roofline
 
+    def reference_frame():
+        """The reference's own frame through the drop-in entry point: 1024x1024, 1 spp, depth 2
+        (constants.rs:9-10) — Pipeline::draw_frame of the C++ mirror with the post passes enabled enqueues what the reference
+        records into its one command buffer (pipeline.rs:86-123): ray trace, six denoise dispatches, finalize.  Wall clock per
+        frame, frames enqueued back to back behind the mirror's per-frame fence (one frame in flight, as the reference), and the
+        stages by difference (ray trace only / + denoise / + finalize)."""
+        g = render.Game()
+        g.generate_world(rt_world.DEFAULT_SEED)
+        out = {"workload": "1024x1024 spp=1 depth=2 + denoise x6 + finalize (the reference's frame, pipeline.rs:86-123)", "frames": 200}
+
+        def run(post, frames=200):
+            cfg = render.make_config(1024, 1024, spp=1, depth=2, device=local_rank, kernel=kernel, flags=abi.RT_FLAG_CACHE_PRIMARY)
+            pipe = render.create_instance(cfg, g, noise)
+            if post:
+                pipe.enable_post_passes(faithful=True)
+            for _ in range(10):
+                pipe.draw_frame(g)
+            pipe.wait()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                pipe.draw_frame(g)       # waits for the previous frame first (pipeline.rs:162-172)
+            pipe.wait()
+            ms = (time.perf_counter() - t0) * 1e3 / frames
+            sha = hashlib.sha256(pipe.context.readback(abi.RT_BUF_FINAL_BGRA8).tobytes()).hexdigest()[:16] if post else None
+            pipe.close()
+            return ms, sha
+
+        rt_ms, _ = run(False)
+        full_ms, sha = run(True)
+        out["ms_per_frame"] = round(full_ms, 4)
+        out["raytrace_ms"] = round(rt_ms, 4)
+        out["post_passes_ms"] = round(full_ms - rt_ms, 4)
+        out["final_image_sha256_16"] = sha
+        # the same frames through the C ABI without the mirror's fence: two frames in flight, post passes on the frame's own stream
+        cfg = render.make_config(1024, 1024, spp=1, depth=2, device=local_rank, kernel=kernel, flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_FRAMES_IN_FLIGHT_2)
+        with render.Context(cfg) as c2:
+            c2.upload_world(mats, mine)
+            c2.upload_noise(noise)
+            u1 = render.camera_uniforms(render.DEFAULT_POSE["origin"], render.DEFAULT_POSE["heading"], render.DEFAULT_POSE["pitch"], render.DEFAULT_POSE["sun_angle"], seed=1)
+            for post in (False, True):
+                for it in range(2):
+                    t0 = time.perf_counter()
+                    for _ in range(200):
+                        c2.draw_frame(u1)
+                        if post:
+                            c2.denoise(True)
+                            c2.finalize()
+                    c2.sync()
+                    ms = (time.perf_counter() - t0) * 1e3 / 200
+                out["two_in_flight_%s_ms" % ("full" if post else "raytrace")] = round(ms, 4)
+        g.close()
+        return out
+
     W, H, SPP, D = args.width, args.height, args.spp, args.depth
     rec = measure(W, H, SPP, D, args.steps, args.warmup)
     c4 = None
@@ -394,6 +469,10 @@ def main():
                                                                                               else "serial on the render stream"))
                                                            if rccl else "host-staged (%s rehearsal)" % backend),
                        "reserve_cus": reserve_cus,
+                       # frames the K timed steps keep in flight (frame slots) and path launches in flight (streams the library
+                       # alternates its launches between); ms_per_step is the throughput figure, latency_ms_one_frame = draw + wait alone
+                       "frames_in_flight": int(rec["frames_in_flight"]), "launches_in_flight": int(rec["launches_in_flight"]),
+                       "latency_ms_one_frame": None if rec["latency_ms"] is None else round(rec["latency_ms"], 4),
                        # footprint of rank 0's context: samples one path-kernel launch covers and what its light records take
                        # (sized for min(16 GiB, a tenth of the free memory) unless RT_PERSIST_LIGHT_GIB says otherwise)
                        "samples_per_launch": int(rec["samples_per_launch"]), "light_record_bytes": int(rec["light_record_bytes"]),
@@ -402,6 +481,12 @@ def main():
         }
         if c4 is not None:
             out["c4"] = c4
+        if dist_on and rec["gathers"]:
+            # rank 0's rt_gather_gbuffer calls alone (events round transfer + un-tile on their stream): separates render, drain and gather
+            out["gather"] = {"ms_per_frame": round(rec["gather_ms"] / rec["gathers"], 4), "calls": int(rec["gathers"]), "rank": 0,
+                             "bytes_to_root_per_frame": int(W * H * 23)}
+        if world == 1 and not dist_on and not args.no_reference_frame and not args.share_of and REGION == 256 and LR == (0, 0, 0):
+            out["reference_frame"] = reference_frame()
         if not args.no_cpu_baseline:
             # rank 0's host cores, after the timed region (the other ranks wait at the closing barrier); a shorter sample at N > 1
             out["cpu_baseline"] = cpu_baseline(mats, mine, noise, uniforms(args.seed), W, H, SPP, D, int(rec["rays_total"]),

@@ -101,8 +101,7 @@ typedef enum RtKernel {
     RT_KERNEL_PATHS = 5,      /* a lane carries two paths with two ray slots each (four fetch chains in flight per lane) and
                                  the step loop is branch-free; frames it does not cover (no primary cache)
                                  run on RT_KERNEL_PERSISTENT                                                     */
-    RT_KERNEL_SEQ = 6         /* branch-free like PATHS, but a lane carries three paths with ONE slot each that walks the
-                                 level's shadow ray and then its diffuse ray (fuller slots); region 256 only      */
+    /* 6 was RT_KERNEL_SEQ (three paths per lane, one ray slot each): retired in round 4 (ABI 1.2), rejected by rt_create */
 } RtKernel;
 
 #define RT_FLAG_COUNTERS      0x1u  /* count rays/iterations/hits exactly (slower; for B_alg + parity)   */
@@ -111,6 +110,16 @@ typedef enum RtKernel {
 #define RT_FLAG_TIMING_ALL    0xCu  /* ... and every other launch and the frame as well (shade_ms, frame_ms); includes RT_FLAG_TIMING */
 #define RT_FLAG_TRUSTED_WORLD 0x10u /* rt_upload_slice: the host vouches that every minefield value is <= 30 (the reference
                                        writes 0..6); the slab is applied without the host-side scan of its bytes        */
+#define RT_FLAG_FRAMES_IN_FLIGHT_2 0x20u /* (ABI 1.2) two frames in flight: consecutive rt_draw_frame calls render into two frame
+                                       slots (two sets of output planes) on two streams, so that frame k + 1's kernels take the CUs
+                                       frame k's draining path kernel leaves — the reference keeps one frame in flight behind its
+                                       fence (pipeline.rs:162-172), and a host that waits (rt_sync) after every frame sees no
+                                       difference.  What changes for a host that does not: rt_device_ptr / rt_gbuffer_ptr return
+                                       the planes of the frame drawn LAST and alternate from frame to frame (the planes of frame k
+                                       stay intact until frame k + 2 is drawn); rt_readback, rt_denoise, rt_finalize and
+                                       rt_gather_gbuffer act on the frame drawn last and are ordered after it; rt_sync waits for
+                                       every frame.  Persistent kernels (DEFAULT / PERSISTENT / PATHS) on the context's own stream
+                                       only: ignored elsewhere and after rt_set_stream(non-NULL).                          */
 
 /*
  * RtConfig — replaces the compile-time window constants (constants.rs:9-10) and adds the
@@ -194,10 +203,13 @@ typedef struct RtInfo {
     uint32_t struct_size;               /* = sizeof(RtInfo), set by the caller                                              */
     int32_t  num_cus;                   /* CUs the persistent kernels launch on (RT_RESERVE_CUS subtracted)                 */
     uint32_t samples_per_launch;        /* samples of every pixel one path-kernel launch covers (spp / this = launches)     */
-    uint32_t reserved;
-    uint64_t light_record_budget_bytes; /* what the per-path light records were sized for: min(16 GiB, free / 10) or
-                                           RT_PERSIST_LIGHT_GIB                                                            */
-    uint64_t light_record_bytes;        /* ... and what they take                                                          */
+    uint16_t launches_in_flight;        /* (ABI 1.2; was reserved = 0) path launches the context keeps in flight: 2 = its launches
+                                           alternate between two streams (sample batches of a frame; frames too with
+                                           RT_FLAG_FRAMES_IN_FLIGHT_2), 1 otherwise                                          */
+    uint16_t frames_in_flight;          /* (ABI 1.2) frame slots: 2 with RT_FLAG_FRAMES_IN_FLIGHT_2                          */
+    uint64_t light_record_budget_bytes; /* what the per-path light records were sized for, all launches in flight together:
+                                           min(default, free / 10) or RT_PERSIST_LIGHT_GIB                                  */
+    uint64_t light_record_bytes;        /* ... and what they take (all launches in flight)                                  */
     uint64_t device_bytes;              /* all device memory the context holds                                             */
 } RtInfo;
 
@@ -239,6 +251,12 @@ int rt_slice_staging(RtContext* ctx, uint32_t** materials, uint8_t** minefield);
 
 /* Allocation figures of the context (see RtInfo). */
 int rt_get_info(RtContext* ctx, RtInfo* out);
+
+/* (ABI 1.2) The launch-sizing rule behind RtInfo.samples_per_launch, as a pure function (no device needed): samples of every
+ * pixel one path-kernel launch covers when `lane_bytes` are given to the 12-byte light records of ONE launch (the context's
+ * budget divided by its launches in flight, RtInfo.launches_in_flight) and the frame queues `npix` pixels: at most 2^31 paths,
+ * at most `spp`, at least 1; `env_batch` (the RT_PERSIST_BATCH string, or NULL) may only lower it. */
+uint64_t rt_samples_per_launch(uint64_t lane_bytes, uint64_t npix, uint64_t spp, const char* env_batch);
 
 /* Blue-noise table (render_data.rs:110-133; decoded by structures.rs:496-517): RGBA8 512x512. */
 int rt_upload_noise(RtContext* ctx, const uint8_t* rgba8);
@@ -327,7 +345,7 @@ int rt_finalize_planes(RtContext* ctx, const void* albedo_rgba8, const void* emi
                        const void* lighting_rgba16, const void* depth_r16, void* out_bgra8);
 
 /* The traversal implementation the context runs: after a frame, the kernel its path launches actually ran on (RT_KERNEL_DEFAULT
- * and RT_KERNEL_PATHS/SEQ choose per frame: launch size, lr, primary cache, region); before the first frame, what the
+ * and RT_KERNEL_PATHS choose per frame: launch size, lr, primary cache, region); before the first frame, what the
  * configuration resolved to.  Negative RtStatus on a null context. */
 int rt_kernel_in_use(RtContext* ctx);
 
@@ -340,8 +358,23 @@ int rt_selftest(RtContext* ctx, int which, uint64_t* result);
 int rt_get_counters(RtContext* ctx, RtCounters* out);
 int rt_reset_counters(RtContext* ctx);
 int rt_get_timing(RtContext* ctx, RtTiming* out);
+/* (ABI 1.2) Device time of the rt_gather_gbuffer calls since the previous call of this function: *ms_sum = sum over the calls of
+ * (transfer + un-tile), from HIP events recorded round them on the stream they run on, *calls = how many.  On a rank that is
+ * not the root the time includes waiting for the root to post its receive.  Contexts created with RT_FLAG_TIMING; otherwise 0, 0.
+ * Waits for the context's streams. */
+int rt_get_gather_timing(RtContext* ctx, float* ms_sum, uint32_t* calls);
 
-/* Library/ABI version: (major<<16)|minor. */
+/* Library/ABI version: (major<<16)|minor.  History of the minor version (a host bound against an older header keeps working
+ * within a major version; it cannot rely on what a later minor added):
+ *   1.0  rounds 1-2.
+ *   1.1  round 3: rt_slice_staging, rt_get_info / RtInfo; RtKernel value 4 (PERSISTENT2) rejected by rt_create; RtTiming.frame_ms
+ *        is 0 unless RT_FLAG_TIMING_ALL; rt_upload_slice asynchronous, validates on the host BEFORE applying, and a rejected slab
+ *        no longer makes rt_draw_frame fail.
+ *   1.2  round 4: RT_FLAG_FRAMES_IN_FLIGHT_2; RtInfo.launches_in_flight / frames_in_flight (in the former `reserved` word);
+ *        rt_samples_per_launch, rt_get_gather_timing; RtKernel value 6 (SEQ) rejected by rt_create; the sample batches of a multi-launch frame run on two
+ *        streams of the library (results unchanged; rt_set_stream(non-NULL) keeps everything on the caller's stream). */
+#define RT_ABI_VERSION_MAJOR 1
+#define RT_ABI_VERSION_MINOR 2
 uint32_t rt_abi_version(void);
 
 #ifdef __cplusplus

@@ -18,7 +18,7 @@ ABI_SYMBOLS = (
     "rt_untile_gbuffer", "rt_denoise", "rt_finalize", "rt_denoise_planes", "rt_finalize_planes", "rt_kernel_in_use", "rt_get_counters", "rt_reset_counters", "rt_get_timing",
     "rt_abi_version",
     "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_gather_gbuffer", "rt_frame_ptr",
-    "rt_frame_readback", "rt_selftest", "rt_get_info",
+    "rt_frame_readback", "rt_selftest", "rt_get_info", "rt_samples_per_launch", "rt_get_gather_timing",
 )
 
 _amd = None
@@ -80,6 +80,10 @@ def amd():
         lib.rt_get_info.argtypes = [P, C.POINTER(RtInfo)]
         lib.rt_get_info.restype = C.c_int
         lib.rt_abi_version.restype = C.c_uint32
+        lib.rt_samples_per_launch.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p]
+        lib.rt_samples_per_launch.restype = C.c_uint64
+        lib.rt_get_gather_timing.argtypes = [P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        lib.rt_get_gather_timing.restype = C.c_int
         lib.rt_comm_unique_id.argtypes = [P, C.c_size_t]
         lib.rt_comm_init_rank.argtypes = [P, P, C.c_size_t, C.POINTER(P)]
         lib.rt_comm_init_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(P)]
@@ -173,6 +177,8 @@ def host():
         lib.rth_pipeline_context.restype = P
         lib.rth_pipeline_uniforms.argtypes = [P, C.POINTER(RtUniforms)]
         lib.rth_pipeline_set_seed.argtypes = [P, C.c_uint32]
+        lib.rth_pipeline_enable_post_passes.argtypes = [P, C.c_int]
+        lib.rth_pipeline_enable_post_passes.restype = C.c_int
         lib.rth_pipeline_last_error.argtypes = [P]
         lib.rth_pipeline_last_error.restype = C.c_char_p
         _host = lib

@@ -20,7 +20,8 @@ RT_ERR_UNIMPLEMENTED = -5
 RT_ERR_OOM = -6
 
 RT_FLAG_TRUSTED_WORLD = 0x10
-RT_KERNEL_DEFAULT, RT_KERNEL_MEGA, RT_KERNEL_WAVEFRONT, RT_KERNEL_PERSISTENT, RT_KERNEL_PATHS, RT_KERNEL_SEQ = 0, 1, 2, 3, 5, 6   # 4: retired
+RT_KERNEL_DEFAULT, RT_KERNEL_MEGA, RT_KERNEL_WAVEFRONT, RT_KERNEL_PERSISTENT, RT_KERNEL_PATHS = 0, 1, 2, 3, 5   # 4 (PERSISTENT2) and 6 (SEQ): retired
+RT_FLAG_FRAMES_IN_FLIGHT_2 = 0x20
 RT_FLAG_COUNTERS = 0x1
 RT_FLAG_CACHE_PRIMARY = 0x2
 RT_FLAG_TIMING = 0x4
@@ -94,7 +95,7 @@ class RtCounters(C.Structure):
 
 
 class RtInfo(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32), ("num_cus", C.c_int32), ("samples_per_launch", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32), ("num_cus", C.c_int32), ("samples_per_launch", C.c_uint32), ("launches_in_flight", C.c_uint16), ("frames_in_flight", C.c_uint16),
                 ("light_record_budget_bytes", C.c_uint64), ("light_record_bytes", C.c_uint64), ("device_bytes", C.c_uint64)]
 
 

@@ -29,14 +29,42 @@ const size_t kBytesPerPixel[RT_BUF_COUNT] = {8, 2, 1, 4, 4, 4, 16, 16, 4, 4};
 }  // namespace
 
 constexpr size_t kCursorWords = 8 * 32;   // path cursors of the persistent kernels: one word per XCD group, each on its own 128-byte line
-// A cursor SET = the eight cursor lines + the worklist count on a line of its own.  There are two: frame n works on set n & 1 while
-// its prepass clears the other one for frame n + 1 (no memset in front of every frame).
-constexpr size_t kCursorSetWords = kCursorWords + 32;
 // RT_KERNEL_DEFAULT: launches of at least this many pixel-samples run on k_paths, smaller ones on k_persist (measured crossover,
 // round 3, same box: 1080p spp 1 (2.1 M) 0.351 against 0.348 ms per frame, spp 2 (4.1 M) 0.409 against 0.442; 1024^2 spp 1 0.252 against 0.229)
 constexpr uint64_t kPathsCrossover = 3ull << 20;
 // light records of one launch above which k_paths streams them out and k_accumulate_paths streams them in (see rt_draw_frame)
 constexpr uint64_t kStreamRecordBytes = 384ull << 20;
+
+// Round 4 — two launches in flight.  A persistent path launch ends in a drain: its workgroups finish 0.1-0.25 ms
+// apart and each holds its CU (all 512 VGPRs of every SIMD, 158 KiB of LDS) until its last wave has ended, so the next launch on
+// the same stream finds the GPU half empty for that long (profiles/r4_wg_end_times.txt).  The library therefore alternates its
+// path launches between two LANES — a stream with everything a launch writes while it runs: cursors, albedo stack, light
+// records — so that the workgroups of launch n + 1 take the CUs launch n's workgroups leave: the sample batches of one frame
+// (always), and with RT_FLAG_FRAMES_IN_FLIGHT_2 the frames themselves, which then render into two FRAME SLOTS (G-buffer planes,
+// worklist, primary hits, per-pixel sums) used in turn.  Ordering is by events on the device; the host waits for nothing.
+struct Lane {
+    hipStream_t stream = nullptr;      // lane 0: the context's stream (its own or the caller's, rt_set_stream); lane 1: the library's second stream
+    uint32_t* cursor = nullptr;        // kCursorWords: eight path cursors, one 128-byte line each
+    bool cursor_clean = false;         // all zero (create-time memset, or the prepass in front of the launch cleared it)
+    uint32_t* pstack = nullptr;        // albedo stack of the launch in flight (global part)
+    rtd::PathLight* ppl = nullptr;     // light records of the launch in flight
+    hipEvent_t ev_join = nullptr;      // "everything submitted to this lane so far" (join_lanes_into)
+};
+struct FrameSlot {
+    void* planes[RT_BUF_COUNT] = {};
+    void* gbuffer = nullptr;           // planes 0..5 back to back (256-byte aligned each)
+    uint32_t* worklist = nullptr;
+    float4* phit = nullptr;            // primary-hit records of the worklist (rtd::PrimaryArgs::phit)
+    float4* pacc = nullptr;
+    uint32_t* wl_count = nullptr;      // two words on lines of their own: the frame in the slot counts in [wl_parity] while its prepass clears the other
+    int wl_parity = 0;
+    bool wl_clean[2] = {false, false};
+    void* denoise_work[2] = {nullptr, nullptr};   // ping/pong working planes of the denoise passes (16 B/pixel), allocated on first use
+    hipEvent_t ev_prepass = nullptr;   // the frame's prepass and tables are done (launches on the other lane wait for it)
+    hipEvent_t ev_acc = nullptr;       // the frame's most recent accumulate launch (the next one adds to the same sums, in sample order)
+    hipEvent_t ev_tail = nullptr;      // everything submitted for the frame in this slot: the slot's next frame starts after it
+    bool tail_recorded = false;
+};
 
 struct RtContext {
     RtConfig cfg{};
@@ -45,7 +73,8 @@ struct RtContext {
     int logr = 8;                       // log2 of the region edge
     int region = RT_ROOT_BLOCK_SIZE;    // R
     size_t vox = 0;                     // R^3
-    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr;   // stream: where the frame drawn last ended (post passes, gather, readback follow it there)
+    bool user_stream = false;           // rt_set_stream gave a stream: one lane, one slot
     std::string err = "";
     bool has_world = false, has_noise = false;
     bool world_resident = false;          // a full region has been uploaded once (slabs may patch it)
@@ -66,11 +95,20 @@ struct RtContext {
     uint32_t npix_pad = 0;     // ntiles_local * 64
     size_t plane_pixels = 0;   // pixels per output plane
 
+    // the planes of the frame drawn last (aliases of its slot's: rt_device_ptr, rt_readback, the post passes and the gather use them)
     void* planes[RT_BUF_COUNT] = {};
-    void* gbuffer = nullptr;            // planes 0..5 back to back (256-byte aligned each)
+    void* gbuffer = nullptr;
     size_t gbuffer_offset[6] = {};
     size_t gbuffer_bytes = 0;
-    void* denoise_work[2] = {nullptr, nullptr};   // ping/pong working planes of the denoise passes (16 B/pixel), allocated on first use
+    Lane lanes[2];
+    int nlanes = 1;                     // 2: path launches alternate between two streams (persistent kernels on the context's own stream)
+    FrameSlot slots[2];
+    int nslots = 1;                     // 2 with RT_FLAG_FRAMES_IN_FLIGHT_2
+    int cur_slot = 0;                   // slot of the frame drawn last
+    uint64_t frames_drawn = 0, path_launches = 0;
+    hipEvent_t ev_fence = nullptr;      // fence_lanes_after
+    hipEvent_t ev_gather = nullptr;     // the previous rt_gather_gbuffer (gathers share staging: they run one after the other)
+    bool gather_recorded = false;
 
     // wavefront pipeline state
     int kernel = RT_KERNEL_PERSISTENT;
@@ -86,24 +124,15 @@ struct RtContext {
     uint32_t *sunbits = nullptr, *stack = nullptr;
     float4* acc = nullptr;
     uint32_t* ctrl = nullptr;     // per batch: [RT_MAX_DEPTH+2] pair counts, then [RT_MAX_DEPTH+2] cursors
-    // persistent kernel state
-    uint32_t* pcursor = nullptr;   // two cursor sets: [0, kCursorWords) path cursors (one per XCD group), [kCursorWords] worklist count
-    int cursor_set = 0;            // the set the next frame works on
-    bool cursor_set_clean[2] = {false, false};   // all zero (by the create-time memset or by the previous frame's prepass)
-    uint32_t* pstack = nullptr;
-    uint32_t* worklist = nullptr;
-    float4* phit = nullptr;        // primary-hit records of the worklist (rtd::PrimaryArgs::phit)
+    // persistent kernel state (per-launch and per-frame buffers live in the lanes and slots above)
     float4* sphere_lut = nullptr;
     float4* sun_lut = nullptr;
     float4* dif_lut = nullptr;
-    float4* pacc = nullptr;
-    rtd::PathLight* ppl = nullptr;
     uint32_t persist_batch = 1;
     int pl_stream_mode = -1;      // RT_PL_STREAM: -1 = by size (kStreamRecordBytes); bit 0 streaming stores, bit 1 streaming loads
     uint32_t persist_chunk = 0;   // RT_PERSIST_CHUNK: paths per cursor atomic (multiple of 64); 0 = automatic
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
-    int persist_version = 1;      // 1 = k_persist, 3 = k_paths (RT_KERNEL_PATHS), 4 = k_seq (RT_KERNEL_SEQ)
-    int seq_nc = 2;               // k_seq: paths per lane (RT_SEQ_NC; 2 measured faster than 3)
+    int persist_version = 1;      // 1 = k_persist, 3 = k_paths (RT_KERNEL_PATHS)
     bool paths_by_size = false;   // RT_KERNEL_DEFAULT: k_paths for launches with enough work, k_persist for small ones
     int last_path_kernel = 0;     // RtKernel the most recent frame's path launches ran on (0 = no frame yet)
     float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
@@ -131,6 +160,8 @@ struct RtContext {
     bool ev_free_recorded[2] = {false, false};
     uint64_t gathers = 0;
     uint32_t timer_overflow = 0;   // launches that found the event pool full (RT_FLAG_TIMING without rt_get_timing)
+    std::vector<hipEvent_t> gather_ev;   // RT_FLAG_TIMING: (start, stop) pairs round the rt_gather_gbuffer calls (rt_get_gather_timing)
+    size_t gather_ev_used = 0;
 
     std::vector<void*> allocs;
     uint64_t device_bytes = 0;       // sum of the context's device allocations (rt_get_info)
@@ -169,19 +200,20 @@ rtd::Scene scene_of(const RtContext* c) {
     return s;
 }
 
-rtd::Planes planes_of(const RtContext* c) {
+rtd::Planes planes_of(void* const* planes) {
     rtd::Planes p;
-    p.lighting_rgba16 = (uint16_t*)c->planes[RT_BUF_LIGHTING_RGBA16];
-    p.depth_r16 = (uint16_t*)c->planes[RT_BUF_DEPTH_R16UI];
-    p.normal_r8 = (uint8_t*)c->planes[RT_BUF_NORMAL_R8UI];
-    p.albedo_rgba8 = (uint32_t*)c->planes[RT_BUF_ALBEDO_RGBA8];
-    p.emission_rgba8 = (uint32_t*)c->planes[RT_BUF_EMISSION_RGBA8];
-    p.fog_rgba8 = (uint32_t*)c->planes[RT_BUF_FOG_RGBA8];
-    p.lighting_f32 = (float*)c->planes[RT_BUF_LIGHTING_F32];
-    p.fog_f32 = (float*)c->planes[RT_BUF_FOG_F32];
-    p.depth_f32 = (float*)c->planes[RT_BUF_DEPTH_F32];
+    p.lighting_rgba16 = (uint16_t*)planes[RT_BUF_LIGHTING_RGBA16];
+    p.depth_r16 = (uint16_t*)planes[RT_BUF_DEPTH_R16UI];
+    p.normal_r8 = (uint8_t*)planes[RT_BUF_NORMAL_R8UI];
+    p.albedo_rgba8 = (uint32_t*)planes[RT_BUF_ALBEDO_RGBA8];
+    p.emission_rgba8 = (uint32_t*)planes[RT_BUF_EMISSION_RGBA8];
+    p.fog_rgba8 = (uint32_t*)planes[RT_BUF_FOG_RGBA8];
+    p.lighting_f32 = (float*)planes[RT_BUF_LIGHTING_F32];
+    p.fog_f32 = (float*)planes[RT_BUF_FOG_F32];
+    p.depth_f32 = (float*)planes[RT_BUF_DEPTH_F32];
     return p;
 }
+rtd::Planes planes_of(const RtContext* c) { return planes_of(c->planes); }
 
 // raytrace.comp:317-318 — uniform over the frame, so evaluated once here with the same rt_math.h the kernels use.
 void sun_constants(float a, float* sunangle, float* sunlight) {
@@ -218,12 +250,13 @@ rtd::Frame frame_of(const RtContext* c, const RtUniforms* u) {
     return f;
 }
 
-// Event pair bracketing one launch (only with RT_FLAG_TIMING).
+// Event pair bracketing one launch (only with RT_FLAG_TIMING), recorded on the stream the launch goes to.
 struct LaunchTimer {
-    RtContext* c; bool on; size_t idx;
+    RtContext* c; bool on; size_t idx; hipStream_t st;
     // kind 0 = traversal kernel (RT_FLAG_TIMING), 1 = any other launch (RT_FLAG_TIMING_ALL: each pair of events costs a few us)
-    LaunchTimer(RtContext* ctx, int kind)
-        : c(ctx), on(kind == 0 ? (ctx->cfg.flags & RT_FLAG_TIMING) != 0 : (ctx->cfg.flags & RT_FLAG_TIMING_ALL) == RT_FLAG_TIMING_ALL), idx(0) {
+    LaunchTimer(RtContext* ctx, int kind, hipStream_t stream = nullptr)
+        : c(ctx), on(kind == 0 ? (ctx->cfg.flags & RT_FLAG_TIMING) != 0 : (ctx->cfg.flags & RT_FLAG_TIMING_ALL) == RT_FLAG_TIMING_ALL), idx(0),
+          st(stream ? stream : ctx->stream) {
         if (!on) return;
         if (c->ev_used + 2 > kMaxTimerEvents) { c->timer_overflow++; on = false; return; }
         if (c->ev_used + 2 > c->ev_pool.size()) {
@@ -232,10 +265,38 @@ struct LaunchTimer {
         idx = c->ev_used; c->ev_used += 2;
         if (c->ev_kind.size() < c->ev_used / 2) c->ev_kind.resize(c->ev_used / 2);
         c->ev_kind[idx / 2] = kind;
-        (void)hipEventRecord(c->ev_pool[idx], c->stream);
+        (void)hipEventRecord(c->ev_pool[idx], st);
     }
-    ~LaunchTimer() { if (on) (void)hipEventRecord(c->ev_pool[idx + 1], c->stream); }
+    ~LaunchTimer() { if (on) (void)hipEventRecord(c->ev_pool[idx + 1], st); }
 };
+
+// ---- lanes (round 4): ordering between the library's streams, all on the device -------------------------------------------
+// `st` waits for everything submitted so far on the other lanes (and on the stream the last frame ended on)
+hipError_t join_lanes_into(RtContext* c, hipStream_t st) {
+    for (int l = 0; l < c->nlanes; l++) {
+        Lane& ln = c->lanes[l];
+        if (ln.stream == st || !ln.stream) continue;
+        hipError_t e = hipEventRecord(ln.ev_join, ln.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ln.ev_join, 0);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+// ... and the other lanes wait for what `st` holds now
+hipError_t fence_lanes_after(RtContext* c, hipStream_t st) {
+    if (c->nlanes < 2) return hipSuccess;
+    hipError_t e = hipEventRecord(c->ev_fence, st);
+    for (int l = 0; l < c->nlanes && e == hipSuccess; l++)
+        if (c->lanes[l].stream != st) e = hipStreamWaitEvent(c->lanes[l].stream, c->ev_fence, 0);
+    return e;
+}
+// host-side wait for every stream of the context that renders
+hipError_t sync_lanes(RtContext* c) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    for (int l = 0; l < c->nlanes && e == hipSuccess; l++)
+        if (c->lanes[l].stream && c->lanes[l].stream != c->stream) e = hipStreamSynchronize(c->lanes[l].stream);
+    return e;
+}
 
 int reflatten(RtContext* c, const uint8_t* d_mine_lin, const uint32_t* d_mat_lin) {
     RT_HIP(c, hipMemsetAsync(c->d_flag, 0, sizeof(uint32_t), c->stream));
@@ -295,9 +356,32 @@ int draw_wavefront(RtContext* c, const rtd::Frame& f) {
 
 }  // namespace
 
+// Light-record budget of a context (all lanes together): RT_PERSIST_LIGHT_GIB, else min(kDefaultLightBytes, a tenth of the free
+// device memory): a context is one tenant of the GPU.  Pure function of its inputs apart from hipMemGetInfo.
+constexpr uint64_t kDefaultLightBytes = 16ull << 30;
+uint64_t rt_light_budget_bytes(const char* env_gib) {
+    uint64_t light_bytes = kDefaultLightBytes;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { if ((uint64_t)free_b / 10u < light_bytes) light_bytes = (uint64_t)free_b / 10u; }
+    else (void)hipGetLastError();
+    if (env_gib) { long long v = atoll(env_gib); if (v >= 1 && v <= 128) light_bytes = (uint64_t)v << 30; }
+    return light_bytes;
+}
+// Samples of every pixel one launch covers: what `lane_bytes` of 12-byte records hold for `npix` worklist slots, at most 2^31
+// paths (path indices are 32-bit), at most spp, at least 1; RT_PERSIST_BATCH may only lower it.  (tests/test_abi.py pins it.)
+extern "C" uint64_t rt_samples_per_launch(uint64_t lane_bytes, uint64_t npix, uint64_t spp, const char* env_batch) {
+    if (npix == 0) npix = 1;
+    uint64_t B = lane_bytes / (sizeof(rtd::PathLight) * npix);
+    if (B > (1ull << 31) / npix) B = (1ull << 31) / npix;
+    if (env_batch) { long long v = atoll(env_batch); if (v > 0 && (uint64_t)v < B) B = (uint64_t)v; }
+    if (B < 1) B = 1;
+    if (B > spp) B = spp;
+    return B;
+}
+
 extern "C" {
 
-uint32_t rt_abi_version(void) { return (1u << 16) | 0u; }
+uint32_t rt_abi_version(void) { return ((uint32_t)RT_ABI_VERSION_MAJOR << 16) | (uint32_t)RT_ABI_VERSION_MINOR; }
 
 const char* rt_last_error(RtContext* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -315,7 +399,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (cfg->depth < 0 || cfg->depth > RT_MAX_DEPTH) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: depth out of range");
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: bad tile_rank/tile_world");
-    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_SEQ || cfg->kernel == 4 /* RT_KERNEL_PERSISTENT2, retired */)
+    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_PATHS || cfg->kernel == 4 /* RT_KERNEL_PERSISTENT2, retired in round 3; 6 = RT_KERNEL_SEQ, round 4 */)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown kernel");
 
     int ndev = 0;
@@ -342,8 +426,6 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         c->paths_by_size = cfg->kernel == RT_KERNEL_DEFAULT;
         c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PATHS : cfg->kernel;
         if (c->kernel == RT_KERNEL_PATHS) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 3; }
-        if (c->kernel == RT_KERNEL_SEQ) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 4; }
-        if (const char* s = getenv("RT_SEQ_NC")) { int v = atoi(s); if (v == 2 || v == 3) c->seq_nc = v; }
     }
     RT_HIP_CREATE(hipSetDevice(c->device));
     hipDeviceProp_t prop;
@@ -374,7 +456,21 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     RT_HIP_CREATE(dev_alloc(c, &c->d_counters, 1));
     RT_HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(rtd::DevCounters)));
 
-    {   // the six reference-format planes live in ONE block (each padded to 256 B) so a multi-GPU host can gather them
+    // lanes and frame slots (see Lane / FrameSlot).  Two lanes for the persistent kernels; two slots when the host asks for two
+    // frames in flight.  RT_LANES=1 / RT_FRAMES_IN_FLIGHT=1|2 override (experiments, A/B timing).
+    const bool persistent = cfg->kernel == RT_KERNEL_DEFAULT || cfg->kernel == RT_KERNEL_PERSISTENT || cfg->kernel == RT_KERNEL_PATHS;
+    c->nlanes = persistent ? 2 : 1;
+    c->nslots = (persistent && (cfg->flags & RT_FLAG_FRAMES_IN_FLIGHT_2)) ? 2 : 1;
+    if (const char* s = getenv("RT_LANES")) { int v = atoi(s); if (v == 1 || (v == 2 && persistent)) c->nlanes = v; }
+    if (const char* s = getenv("RT_FRAMES_IN_FLIGHT")) { int v = atoi(s); if (v == 1 || (v == 2 && persistent)) c->nslots = v; }
+    if (c->nlanes < 2) c->nslots = 1;
+    c->lanes[0].stream = c->own_stream;
+    if (c->nlanes == 2) RT_HIP_CREATE(hipStreamCreateWithFlags(&c->lanes[1].stream, hipStreamNonBlocking));
+    for (int l = 0; l < c->nlanes; l++) RT_HIP_CREATE(hipEventCreateWithFlags(&c->lanes[l].ev_join, hipEventDisableTiming));
+    RT_HIP_CREATE(hipEventCreateWithFlags(&c->ev_fence, hipEventDisableTiming));
+    RT_HIP_CREATE(hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
+
+    {   // the six reference-format planes of a slot live in ONE block (each padded to 256 B) so a multi-GPU host can gather them
         // with a single collective; the other planes are separate allocations
         size_t off = 0;
         for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++) {
@@ -382,17 +478,26 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
             off += (c->plane_pixels * kBytesPerPixel[b] + 255) / 256 * 256;
         }
         c->gbuffer_bytes = off;
-        uint8_t* block = nullptr;
-        RT_HIP_CREATE(dev_alloc(c, &block, off));
-        RT_HIP_CREATE(hipMemset(block, 0, off));
-        c->gbuffer = block;
-        for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++) c->planes[b] = block + c->gbuffer_offset[b];
-        for (int b = RT_BUF_FOG_RGBA8 + 1; b < RT_BUF_COUNT; b++) {
-            uint8_t* p = nullptr;
-            RT_HIP_CREATE(dev_alloc(c, &p, c->plane_pixels * kBytesPerPixel[b]));
-            RT_HIP_CREATE(hipMemset(p, 0, c->plane_pixels * kBytesPerPixel[b]));
-            c->planes[b] = p;
+        for (int sl = 0; sl < c->nslots; sl++) {
+            FrameSlot& fs = c->slots[sl];
+            uint8_t* block = nullptr;
+            RT_HIP_CREATE(dev_alloc(c, &block, off));
+            RT_HIP_CREATE(hipMemset(block, 0, off));
+            fs.gbuffer = block;
+            for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++) fs.planes[b] = block + c->gbuffer_offset[b];
+            for (int b = RT_BUF_FOG_RGBA8 + 1; b < RT_BUF_COUNT; b++) {
+                uint8_t* p = nullptr;
+                RT_HIP_CREATE(dev_alloc(c, &p, c->plane_pixels * kBytesPerPixel[b]));
+                RT_HIP_CREATE(hipMemset(p, 0, c->plane_pixels * kBytesPerPixel[b]));
+                fs.planes[b] = p;
+            }
+            RT_HIP_CREATE(hipEventCreateWithFlags(&fs.ev_prepass, hipEventDisableTiming));
+            RT_HIP_CREATE(hipEventCreateWithFlags(&fs.ev_acc, hipEventDisableTiming));
+            RT_HIP_CREATE(hipEventCreateWithFlags(&fs.ev_tail, hipEventDisableTiming));
         }
+        c->cur_slot = 0;
+        c->gbuffer = c->slots[0].gbuffer;
+        for (int b = 0; b < RT_BUF_COUNT; b++) c->planes[b] = c->slots[0].planes[b];
     }
 
     if (const char* s = getenv("RT_REFILL_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t)v; }
@@ -401,43 +506,44 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (const char* s = getenv("RT_PL_STREAM")) { int v = atoi(s); if (v >= 0 && v <= 3) c->pl_stream_mode = v; }
     if (const char* s = getenv("RT_PERSIST_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= 4096) c->persist_chunk = (uint32_t)v & ~63u; }
     if (const char* s = getenv("RT_PERSIST_RMIN")) { int v = atoi(s); if (v >= 1 && v <= 128) c->persist_rmin = (uint32_t)v; }
-    if (c->persist_version == 4 && !getenv("RT_PERSIST_RMIN")) c->persist_rmin = 16u;   // k_seq: waiting contexts that trigger the re-arm block
     if (c->kernel == RT_KERNEL_PERSISTENT) {
-        RT_HIP_CREATE(dev_alloc(c, &c->pcursor, 2 * kCursorSetWords));   // two sets of 8 cursor lines + the worklist count
-        RT_HIP_CREATE(hipMemset(c->pcursor, 0, 2 * kCursorSetWords * sizeof(uint32_t)));
-        c->cursor_set_clean[0] = c->cursor_set_clean[1] = true;
-        RT_HIP_CREATE(dev_alloc(c, &c->pstack, (size_t)4 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1)));   // up to 3 paths per lane
-        RT_HIP_CREATE(dev_alloc(c, &c->worklist, (size_t)c->npix_pad));
-        RT_HIP_CREATE(dev_alloc(c, &c->phit, (size_t)c->npix_pad));
+        const size_t stack_words = (size_t)4 * c->num_cus * 1024 * (size_t)(cfg->depth > 1 ? cfg->depth - 1 : 1);   // up to 3 paths per lane
+        for (int l = 0; l < c->nlanes; l++) {
+            Lane& ln = c->lanes[l];
+            RT_HIP_CREATE(dev_alloc(c, &ln.cursor, kCursorWords));
+            RT_HIP_CREATE(hipMemset(ln.cursor, 0, kCursorWords * sizeof(uint32_t)));
+            ln.cursor_clean = true;
+            RT_HIP_CREATE(dev_alloc(c, &ln.pstack, stack_words));
+        }
+        for (int sl = 0; sl < c->nslots; sl++) {
+            FrameSlot& fs = c->slots[sl];
+            RT_HIP_CREATE(dev_alloc(c, &fs.wl_count, (size_t)64));   // two counters, 128 bytes apart
+            RT_HIP_CREATE(hipMemset(fs.wl_count, 0, 64 * sizeof(uint32_t)));
+            fs.wl_clean[0] = fs.wl_clean[1] = true;
+            RT_HIP_CREATE(dev_alloc(c, &fs.worklist, (size_t)c->npix_pad));
+            RT_HIP_CREATE(dev_alloc(c, &fs.phit, (size_t)c->npix_pad));
+            RT_HIP_CREATE(dev_alloc(c, &fs.pacc, (size_t)c->npix_pad));
+        }
         RT_HIP_CREATE(dev_alloc(c, &c->sphere_lut, (size_t)65536));
         RT_HIP_CREATE(dev_alloc(c, &c->sun_lut, (size_t)2 * 65536));
         RT_HIP_CREATE(dev_alloc(c, &c->dif_lut, (size_t)4 * 6 * 65536));
-        RT_HIP_CREATE(dev_alloc(c, &c->pacc, (size_t)c->npix_pad));
-        {   // samples per path-kernel launch: bounded by 2^31 work items and by the memory given to the per-path light records —
-            // 16 GiB of the 288 (RT_PERSIST_LIGHT_GIB; 32 GiB: another 0.3-0.5 %): every launch pays its ramp-up and its tail, so fewer and longer ones win
-            // (3840x2160 spp 256 depth 8: 114.1 ms per frame with 1 GiB, 109.3 with 2, 107.0 with 4, 105.6 with 8 and beyond;
-            // the 1024^3 spp-1024 frame: 158.1 with 2 GiB, 138.7 with 8, 136.1 with 32); halved until the allocation succeeds
+        {   // Samples per path-kernel launch: bounded by 2^31 work items and by the memory given to the per-path light records, which
+            // is split between the lanes (a launch's records live until its accumulate launch has read them, and two launches are in
+            // flight).  Round 3 sized one launch for 16 GiB because every launch paid its ramp-up and its drain (3840x2160 spp 256
+            // depth 8: 114.1 ms per frame with 1 GiB, 109.3 with 2, 107.0 with 4, 105.6 with 8 and beyond); with the next launch
+            // taking the CUs the draining one frees, a launch's size matters far less (see kDefaultLightBytes).  Halved until the
+            // allocation succeeds.
             uint64_t np = c->npix_pad ? c->npix_pad : 1;
-            // default: 16 GiB, but never more than a tenth of what is free on the device right now (a context is one tenant of the GPU)
-            uint64_t light_bytes = 16ull << 30;
-            {
-                size_t free_b = 0, total_b = 0;
-                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b / 10u < light_bytes) light_bytes = (uint64_t)free_b / 10u;
-                else (void)hipGetLastError();
-            }
-            if (const char* s = getenv("RT_PERSIST_LIGHT_GIB")) { long long v = atoll(s); if (v >= 1 && v <= 128) light_bytes = (uint64_t)v << 30; }
-            c->light_budget_bytes = light_bytes;
-            uint64_t B = light_bytes / (sizeof(rtd::PathLight) * np);
-            if (B > (1ull << 31) / np) B = (1ull << 31) / np;   // path indices are 32-bit
-            if (const char* s = getenv("RT_PERSIST_BATCH")) { long long v = atoll(s); if (v > 0 && (uint64_t)v < B) B = (uint64_t)v; }   // may only lower the bound
-            if (B < 1) B = 1;
-            if (B > (uint64_t)cfg->spp) B = (uint64_t)cfg->spp;
-            for (;;) {
-                const hipError_t e = dev_alloc(c, &c->ppl, (size_t)np * B);
-                if (e == hipSuccess) break;
-                if (e != hipErrorOutOfMemory || B == 1) RT_HIP_CREATE(e);
-                (void)hipGetLastError();
-                B = (B + 1) / 2;
+            c->light_budget_bytes = rt_light_budget_bytes(getenv("RT_PERSIST_LIGHT_GIB"));
+            uint64_t B = rt_samples_per_launch(c->light_budget_bytes / (uint64_t)c->nlanes, np, (uint64_t)cfg->spp, getenv("RT_PERSIST_BATCH"));
+            for (int l = 0; l < c->nlanes; l++) {
+                for (;;) {
+                    const hipError_t e = dev_alloc(c, &c->lanes[l].ppl, (size_t)np * B);
+                    if (e == hipSuccess) break;
+                    if (e != hipErrorOutOfMemory || B == 1 || l > 0) RT_HIP_CREATE(e);   // (the lanes' buffers have one size)
+                    (void)hipGetLastError();
+                    B = (B + 1) / 2;
+                }
             }
             c->persist_batch = (uint32_t)B;
         }
@@ -479,6 +585,10 @@ void rt_destroy(RtContext* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->stream && ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->lanes[1].stream) { (void)hipStreamSynchronize(ctx->lanes[1].stream); (void)hipStreamDestroy(ctx->lanes[1].stream); }
+    for (Lane& ln : ctx->lanes) if (ln.ev_join) (void)hipEventDestroy(ln.ev_join);
+    for (FrameSlot& fs : ctx->slots) for (hipEvent_t e : {fs.ev_prepass, fs.ev_acc, fs.ev_tail}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->ev_fence, ctx->ev_gather}) if (e) (void)hipEventDestroy(e);
     if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
     if (ctx->ev_slab_copied) (void)hipEventDestroy(ctx->ev_slab_copied);
     if (ctx->ev_slab_applied) (void)hipEventDestroy(ctx->ev_slab_applied);
@@ -486,6 +596,7 @@ void rt_destroy(RtContext* ctx) {
     if (ctx->h_slab_mine) (void)hipHostFree(ctx->h_slab_mine);
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->gather_ev) (void)hipEventDestroy(e);
     if (ctx->ev_frame0) (void)hipEventDestroy(ctx->ev_frame0);
     if (ctx->ev_frame1) (void)hipEventDestroy(ctx->ev_frame1);
     if (ctx->gather_stream) { (void)hipStreamSynchronize(ctx->gather_stream); (void)hipStreamDestroy(ctx->gather_stream); }
@@ -497,10 +608,14 @@ void rt_destroy(RtContext* ctx) {
 int rt_set_stream(RtContext* ctx, void* hip_stream) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, sync_lanes(ctx));
     // NULL selects the context's own (non-blocking) stream, NOT the legacy null stream: work a caller enqueues on the null
-    // stream is not ordered against the context's frames — pass an explicit stream handle to share one
+    // stream is not ordered against the context's frames — pass an explicit stream handle to share one.
+    // On a caller's stream EVERYTHING the context does runs on that stream, in order: no second lane, one frame slot (the
+    // caller's own work on the stream is ordered against the frames by the stream alone).
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->lanes[0].stream = ctx->stream;
+    ctx->user_stream = hip_stream != nullptr;
     return RT_OK;
 }
 
@@ -508,7 +623,7 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (!materials || !minefield) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_world: null pointer");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, sync_lanes(ctx));
     // the caller-layout copy lives for the duration of this call only (it used to stay resident — 160 MiB at
     // R = 256, 5 GiB at R = 1024 — although nothing but this function reads it)
     uint32_t* d_mat_lin = nullptr; uint8_t* d_mine_lin = nullptr;
@@ -592,6 +707,7 @@ int rt_upload_slice(RtContext* ctx, int axis, int texel_offset, const uint32_t* 
     RT_HIP(ctx, hipEventRecord(ctx->ev_slab_copied, ctx->upload_stream));
     ctx->slab_copy_pending = true;
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slab_copied, 0));
+    RT_HIP(ctx, join_lanes_into(ctx, ctx->stream));   // frames in flight on the other lane read the region too
     {
         LaunchTimer t(ctx, 1);
         RT_HIP(ctx, rtd::launch_flatten_slab(ctx->d_slab_mine, ctx->d_slab_mat, ctx->d_mine_sw, ctx->d_mat_sw, ctx->d_coarse,
@@ -599,6 +715,7 @@ int rt_upload_slice(RtContext* ctx, int axis, int texel_offset, const uint32_t* 
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_slab_applied, ctx->stream));
     ctx->slab_apply_recorded = true;
+    RT_HIP(ctx, fence_lanes_after(ctx, ctx->stream));   // ... and later frames, whichever lane they start on, see the slab
     return RT_OK;
 }
 
@@ -606,7 +723,7 @@ int rt_upload_noise(RtContext* ctx, const uint8_t* rgba8) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (!rgba8) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_noise: null pointer");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, sync_lanes(ctx));
     RT_HIP(ctx, hipMemcpy(ctx->d_noise, rgba8, RT_NOISE_BYTES, hipMemcpyHostToDevice));
     ctx->has_noise = true;
     return RT_OK;
@@ -622,58 +739,86 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
     // frame_ms of rt_get_timing: two events per frame, recorded only for a context that asked for every timing — an event between
     // the last kernel of one frame and the first of the next is 4-5 us during which the GPU idles (profiles/r3_frame_timeline.txt)
     const bool frame_events = (ctx->cfg.flags & RT_FLAG_TIMING_ALL) == RT_FLAG_TIMING_ALL;
-    if (frame_events) RT_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
     int rc = RT_OK;
     if (ctx->kernel == RT_KERNEL_MEGA) {
+        if (frame_events) RT_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
         LaunchTimer t(ctx, 0);
         hipError_t e = rtd::launch_mega(scene_of(ctx), f, planes_of(ctx), ctx->d_counters, count, ctx->stream);
         if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("launch_mega: ") + hipGetErrorString(e));
     } else if (ctx->kernel == RT_KERNEL_PERSISTENT) {
         const bool cache = (ctx->cfg.flags & RT_FLAG_CACHE_PRIMARY) != 0;
-        // this frame's cursor set: clean already if the previous frame's prepass cleared it, otherwise cleared here
-        const int set = ctx->cursor_set;
-        uint32_t* const cur = ctx->pcursor + (size_t)set * kCursorSetWords;
-        uint32_t* const nxt = ctx->pcursor + (size_t)(set ^ 1) * kCursorSetWords;
+        const int nl = ctx->user_stream ? 1 : ctx->nlanes, nsl = ctx->user_stream ? 1 : ctx->nslots;
         hipError_t e = hipSuccess;
-        if (!ctx->cursor_set_clean[set]) e = hipMemsetAsync(cur, 0, kCursorSetWords * sizeof(uint32_t), ctx->stream);
-        ctx->cursor_set_clean[set] = false;
-        ctx->cursor_set = set ^ 1;
-        const bool prepass_clears = cache && ctx->primary_version == 2;
+        // What the host put behind the previous frame since (post passes, gather, a slab) belongs to that frame's use of its slot.
+        FrameSlot& prev = ctx->slots[ctx->cur_slot];
+        if (ctx->frame_recorded) { e = hipEventRecord(prev.ev_tail, ctx->stream); prev.tail_recorded = e == hipSuccess; }
+        // This frame's slot, and the lane its prepass and first path launch go to (launches alternate between the lanes).
+        const int si = nsl == 2 ? (int)(ctx->frames_drawn & 1u) : 0;
+        FrameSlot& fs = ctx->slots[si];
+        Lane* L0 = &ctx->lanes[ctx->path_launches % (uint64_t)nl];
+        const hipStream_t st0 = L0->stream;
+        // the frame that used the slot before (frame k - 2 with two slots, k - 1 with one) has finished with it
+        if (e == hipSuccess && fs.tail_recorded) e = hipStreamWaitEvent(st0, fs.ev_tail, 0);
+        if (e == hipSuccess && frame_events) e = hipEventRecord(ctx->ev_frame0, st0);
+        const rtd::Planes fpl = planes_of(fs.planes);
+        // worklist counter of this frame: clean already if the slot's previous frame's prepass cleared it, otherwise cleared here
+        uint32_t* const wlc = fs.wl_count + 32 * fs.wl_parity;
+        uint32_t* const wln = fs.wl_count + 32 * (fs.wl_parity ^ 1);
+        const bool prepass_clears = cache && ctx->primary_version == 2 && ctx->npix_pad != 0;
         if (e == hipSuccess && cache) {
-            LaunchTimer t(ctx, 1);
+            if (!fs.wl_clean[fs.wl_parity]) e = hipMemsetAsync(wlc, 0, sizeof(uint32_t), st0);
+            fs.wl_clean[fs.wl_parity] = false;
+            LaunchTimer t(ctx, 1, st0);
             rtd::PrimaryArgs pr{};
-            pr.phit = ctx->phit;
-            pr.worklist = ctx->worklist; pr.wl_count = cur + kCursorWords; pr.acc = ctx->pacc; pr.counters = ctx->d_counters;
-            pr.zero_words = prepass_clears ? nxt : nullptr; pr.zero_count = (uint32_t)kCursorSetWords;
-            e = rtd::launch_primary(scene_of(ctx), f, planes_of(ctx), pr, count, ctx->primary_version, ctx->num_cus, ctx->stream);
-            ctx->cursor_set_clean[set ^ 1] = prepass_clears && e == hipSuccess && ctx->npix_pad != 0;
+            pr.phit = fs.phit;
+            pr.worklist = fs.worklist; pr.wl_count = wlc; pr.acc = fs.pacc; pr.counters = ctx->d_counters;
+            // the prepass clears what the NEXT users need zeroed instead of a memset of its own in front of them: the slot's other
+            // worklist counter (the slot's next frame) and the path cursors of the lane it runs on (this frame's first launch)
+            pr.zero_words = prepass_clears ? wln : nullptr; pr.zero_count = 1u;
+            pr.zero_words2 = prepass_clears ? L0->cursor : nullptr; pr.zero_count2 = (uint32_t)kCursorWords;
+            if (e == hipSuccess) e = rtd::launch_primary(scene_of(ctx), f, fpl, pr, count, ctx->primary_version, ctx->num_cus, st0);
+            if (prepass_clears && e == hipSuccess) { fs.wl_clean[fs.wl_parity ^ 1] = true; L0->cursor_clean = true; }
+            fs.wl_parity ^= 1;
         }
-        // the two per-frame tables depend on the sun vector and colour only: rebuilt when those change (bit compare)
+        // the two per-frame tables depend on the sun vector and colour only: rebuilt when those change (bit compare) — after every
+        // launch that reads the old ones, on either lane, and before any launch that follows
         float lut_key[6] = {f.sunangle[0], f.sunangle[1], f.sunangle[2], f.sunlight[0], f.sunlight[1], f.sunlight[2]};
         if (e == hipSuccess && ctx->cfg.depth >= 1 && (!ctx->lut_valid || memcmp(lut_key, ctx->lut_key, sizeof(lut_key)) != 0)) {
-            LaunchTimer t(ctx, 1);
-            e = rtd::launch_sun_lut(f, ctx->sun_lut, ctx->stream);
-            if (e == hipSuccess) e = rtd::launch_sky_lut(f, ctx->dif_lut, ctx->stream);
+            if (nl == 2) e = join_lanes_into(ctx, st0);
+            {
+                LaunchTimer t(ctx, 1, st0);
+                if (e == hipSuccess) e = rtd::launch_sun_lut(f, ctx->sun_lut, st0);
+                if (e == hipSuccess) e = rtd::launch_sky_lut(f, ctx->dif_lut, st0);
+            }
+            if (e == hipSuccess && nl == 2) e = fence_lanes_after(ctx, st0);
             ctx->lut_valid = e == hipSuccess;
             memcpy(ctx->lut_key, lut_key, sizeof(lut_key));
         }
-        if (!cache || ctx->cfg.depth >= 1) {
+        hipStream_t tail = st0;
+        if (e == hipSuccess && (!cache || ctx->cfg.depth >= 1)) {
             const uint32_t spp = (uint32_t)ctx->cfg.spp, B = ctx->persist_batch;
+            if (nl == 2 && spp > B) e = hipEventRecord(fs.ev_prepass, st0);   // launches on the other lane wait for the prepass
             // one sample per pixel (the reference's own frames): k_persist and k_paths store the pixel's lighting themselves, no
             // light records and no accumulate launch (raytrace.comp:352-356 has no accumulation either)
             const bool small1 = ctx->paths_by_size && (uint64_t)ctx->npix_pad < kPathsCrossover;   // spp 1: the launch goes to k_persist
             const bool on_paths = ctx->persist_version == 3 && cache && !small1;
-            const bool direct = spp == 1u && ctx->persist_version != 4 && (!on_paths || rtd::launch_paths_direct_ok(f));
+            const bool direct = spp == 1u && (!on_paths || rtd::launch_paths_direct_ok(f));
             for (uint32_t s0 = 0; s0 < spp && e == hipSuccess; s0 += B) {
                 const uint32_t ns = spp - s0 < B ? spp - s0 : B;
-                if (s0 != 0) e = hipMemsetAsync(cur, 0, kCursorWords * sizeof(uint32_t), ctx->stream);
+                // the sample batches of a frame alternate between the lanes: batch b + 1 starts on the CUs batch b's workgroups leave
+                Lane* L = &ctx->lanes[ctx->path_launches % (uint64_t)nl];
+                const hipStream_t st = L->stream;
+                ctx->path_launches++;
+                if (st != st0 && s0 == B) e = hipStreamWaitEvent(st, fs.ev_prepass, 0);   // (later batches on that lane follow by stream order)
+                if (e == hipSuccess && !L->cursor_clean) e = hipMemsetAsync(L->cursor, 0, kCursorWords * sizeof(uint32_t), st);
+                L->cursor_clean = false;
                 rtd::PersistArgs pa{};
-                pa.cursor = cur; pa.worklist = ctx->worklist; pa.wl_count = cur + kCursorWords; pa.direct = direct ? 1u : 0u;
+                pa.cursor = L->cursor; pa.worklist = fs.worklist; pa.wl_count = wlc; pa.direct = direct ? 1u : 0u;
                 pa.npix_pad = ctx->npix_pad; pa.sample0 = s0; pa.nsamples = ns; pa.threshold = ctx->persist_threshold; pa.rmin = ctx->persist_rmin; pa.chunk = ctx->persist_chunk;
-                pa.nthreads = (uint32_t)ctx->num_cus * 1024u; pa.stack = ctx->pstack;
-                pa.phit = ctx->phit;
+                pa.nthreads = (uint32_t)ctx->num_cus * 1024u; pa.stack = L->pstack;
+                pa.phit = fs.phit;
                 pa.sun_lut = ctx->sun_lut; pa.dif_lut = ctx->dif_lut;
-                pa.pl = ctx->ppl; pa.counters = ctx->d_counters;
+                pa.pl = L->ppl; pa.counters = ctx->d_counters;
                 // light records of this launch: streamed past the caches when there are more of them than would stay there until the
                 // accumulate launch reads them (the Infinity Cache holds 256 MB; RT_PL_STREAM = 0 / 1 / 2 / 3 forces never / stores /
                 // loads / both)
@@ -683,43 +828,53 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
                 const bool stream_ld = ctx->pl_stream_mode < 0 ? big_records : (ctx->pl_stream_mode & 2) != 0;
                 pa.pl_stream = stream_st ? 1u : 0u;
                 if (e == hipSuccess) {
-                    LaunchTimer t(ctx, 0);
+                    LaunchTimer t(ctx, 0, st);
                     // k_paths pays for its two contexts per lane once there is enough work to keep them filled: measured
                     // crossover against k_persist (tools/kernel_crossover.sh) between 4 M and 8 M paths per launch — 1080p spp 1:
                     // 0.28 against 0.22 ms, 256^2 spp 64: 0.35 against 0.32, 1080p spp 4: 0.47 against 0.50, spp 16: 1.29 against
                     // 1.65; the reference's own 1024^2 1-spp frame: 0.20 against 0.14.  The worklist length lives on the device;
                     // the pixel count bounds it.  (RT_KERNEL_PATHS asks for k_paths whatever the size.)
                     const bool big = !ctx->paths_by_size || (uint64_t)ctx->npix_pad * ns >= kPathsCrossover;
-                    // parked lanes that trigger a pass (RT_PERSIST_THRESHOLD overrides): measured optima per kernel.  k_persist 32,
-                    // k_seq 36.  k_paths (lanes with a parked context, three steps between looks), round 3, same box: 24 4.28 ms per
+                    // parked lanes that trigger a pass (RT_PERSIST_THRESHOLD overrides): measured optima per kernel.  k_persist 32.
+                    // k_paths (lanes with a parked context, three steps between looks), round 3, same box: 24 4.28 ms per
                     // headline launch, 28 4.22, 32 4.17, 36 4.06-4.15, 40 4.08-4.14, 44 4.12, 48 4.27; deeper frames at region 256 (depth
                     // 5..8: longer paths, fewer new ones per pass) like 40 — 3840x2160 spp 256 depth 8 launch 51.2 ms at 28, 50.7 at 32, 50.0
                     // at 36, 49.6 at 40 and 44 —, the 1024^3 frame stays at 36 (20.74 against 20.86 at 40, 21.2 at 44)
                     const bool to_paths = ctx->persist_version == 3 && cache && big;
                     if (ctx->persist_threshold == 0)
-                        pa.threshold = ctx->persist_version == 4 ? 36u : (!to_paths ? 32u : ((ctx->cfg.depth > 4 && ctx->region == 256) ? 40u : 36u));
-                    if (ctx->persist_version == 4 && cache && f.lr_zero != 0 && f.logr == 8) {
-                        ctx->last_path_kernel = RT_KERNEL_SEQ;
-                        e = rtd::launch_seq(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->seq_nc, ctx->num_cus, ctx->stream);
-                    } else if (ctx->persist_version == 3 && cache && big) {
+                        pa.threshold = !to_paths ? 32u : ((ctx->cfg.depth > 4 && ctx->region == 256) ? 40u : 36u);
+                    if (to_paths) {
                         ctx->last_path_kernel = RT_KERNEL_PATHS;
-                        e = rtd::launch_paths(scene_of(ctx), f, planes_of(ctx), pa, count, ctx->num_cus, ctx->stream);
+                        e = rtd::launch_paths(scene_of(ctx), f, fpl, pa, count, ctx->num_cus, st);
                     } else {
                         ctx->last_path_kernel = RT_KERNEL_PERSISTENT;
+                        e = rtd::launch_persist(scene_of(ctx), f, fpl, pa, count, cache, 1, ctx->num_cus, st);
                     }
-                    if (ctx->last_path_kernel == RT_KERNEL_PERSISTENT)
-                        e = rtd::launch_persist(scene_of(ctx), f, planes_of(ctx), pa, count, cache, 1, ctx->num_cus, ctx->stream);
                 }
                 if (e == hipSuccess && !direct) {
-                    LaunchTimer t(ctx, 1);
-                    e = rtd::launch_accumulate_paths(f, planes_of(ctx), ctx->ppl, ctx->worklist, cur + kCursorWords, ctx->npix_pad, ns,
-                                                     s0 == 0, s0 + B >= spp, cache, stream_ld, ctx->pacc, ctx->stream);
+                    // a pixel's samples are added in sample order: batch b's accumulate follows batch b - 1's, whichever lane that ran on
+                    if (nl == 2 && s0 != 0) e = hipStreamWaitEvent(st, fs.ev_acc, 0);
+                    {
+                        LaunchTimer t(ctx, 1, st);
+                        if (e == hipSuccess)
+                            e = rtd::launch_accumulate_paths(f, fpl, L->ppl, fs.worklist, wlc, ctx->npix_pad, ns, s0 == 0, s0 + B >= spp, cache, stream_ld,
+                                                             fs.pacc, st);
+                    }
+                    if (e == hipSuccess && nl == 2 && s0 + B < spp) e = hipEventRecord(fs.ev_acc, st);
                 }
+                tail = st;
             }
         }
         // (no resolve launch: the prepass and the last accumulate of the frame store the lighting planes themselves)
         if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("persistent path: ") + hipGetErrorString(e));
+        // the frame ends on `tail`: post passes, gather and readback of THIS frame follow it there; its planes are the context's
+        ctx->stream = tail;
+        ctx->cur_slot = si;
+        ctx->gbuffer = fs.gbuffer;
+        for (int b = 0; b < RT_BUF_COUNT; b++) ctx->planes[b] = fs.planes[b];
+        ctx->frames_drawn++;
     } else {
+        if (frame_events) RT_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
         rc = draw_wavefront(ctx, f);
     }
     if (frame_events) RT_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
@@ -731,7 +886,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
 int rt_sync(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, sync_lanes(ctx));
     if (ctx->gather_stream) RT_HIP(ctx, hipStreamSynchronize(ctx->gather_stream));
     return RT_OK;
 }
@@ -776,19 +931,20 @@ int rt_denoise_planes(RtContext* ctx, void* lighting, const void* depth, const v
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int sizes[6] = {1, 2, 4, 8, 8, 16};                         // pipeline.rs:103
     const int W = ctx->cfg.width, H = ctx->cfg.height;
+    void** work = ctx->slots[ctx->cur_slot].denoise_work;   // per slot: the post passes of two frames in flight may overlap
     for (int i = 0; i < 2; i++)
-        if (!ctx->denoise_work[i]) { uint4* p = nullptr; RT_HIP(ctx, dev_alloc(ctx, &p, (size_t)W * H)); ctx->denoise_work[i] = p; }
+        if (!work[i]) { uint4* p = nullptr; RT_HIP(ctx, dev_alloc(ctx, &p, (size_t)W * H)); work[i] = p; }
     {
         LaunchTimer t(ctx, 1);
-        RT_HIP(ctx, rtd::launch_denoise_prepare(lighting, depth, normal, W, H, ctx->denoise_work[0], ctx->stream));
+        RT_HIP(ctx, rtd::launch_denoise_prepare(lighting, depth, normal, W, H, work[0], ctx->stream));
     }
     for (int pass = 0; pass < 6; pass++) {
         // pipeline.rs:104-108: the ping descriptor set on even dispatches, the pong set (normal/depth bindings swapped,
         // descriptor_sets.rs:38-39) on odd ones; the sixth dispatch writes the lighting image finalize.comp reads
         const bool odd = pass % 2 == 1;
         LaunchTimer t(ctx, 1);
-        RT_HIP(ctx, rtd::launch_denoise(ctx->denoise_work[pass & 1], W, H, sizes[pass], odd && faithful != 0, pass == 5,
-                                        ctx->denoise_work[(pass & 1) ^ 1], lighting, ctx->stream));
+        RT_HIP(ctx, rtd::launch_denoise(work[pass & 1], W, H, sizes[pass], odd && faithful != 0, pass == 5,
+                                        work[(pass & 1) ^ 1], lighting, ctx->stream));
     }
     return RT_OK;
 }
@@ -938,9 +1094,12 @@ int rt_gather_gbuffer(RtContext* ctx, void* comm_, int root, void* const* frames
         frames_dev = ctx->frame_planes;
     }
     if (world == 1 && !comm_) {
-        // one context holds the whole frame, row-major already: plain copies on the context's stream
+        // one context holds the whole frame, row-major already: plain copies on the stream the frame ended on, after the previous
+        // frame's copies (which sit on the other lane's stream when two frames are in flight)
+        if (ctx->gather_recorded) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gather, 0));
         for (int b = 0; b <= RT_BUF_FOG_RGBA8; b++)
             if (frames_dev[b]) RT_HIP(ctx, hipMemcpyAsync(frames_dev[b], ctx->planes[b], ctx->plane_pixels * kBytesPerPixel[b], hipMemcpyDeviceToDevice, ctx->stream));
+        RT_HIP(ctx, hipEventRecord(ctx->ev_gather, ctx->stream)); ctx->gather_recorded = true;
         return RT_OK;
     }
     if (!comm_) return fail(ctx, RT_ERR_INVALID_ARG, "rt_gather_gbuffer: null communicator");
@@ -951,6 +1110,9 @@ int rt_gather_gbuffer(RtContext* ctx, void* comm_, int root, void* const* frames
     if (rank == root && !ctx->gathered[s]) RT_HIP(ctx, dev_alloc(ctx, &ctx->gathered[s], gb * (size_t)world));
     hipStream_t gs = ctx->stream;
     const uint8_t* src = (const uint8_t*)ctx->gbuffer;
+    // gathers share the root's staging and the communicator: with two frames in flight the previous frame's gather sits on the
+    // other lane's stream — this one follows it (the frames' rendering still overlaps)
+    if (!overlapped && ctx->gather_recorded) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gather, 0));
     if (overlapped) {
         // The frame's block is copied to one of two staging buffers on the render stream (so the next frame may overwrite the
         // planes), everything else runs on a second stream: frame k's send/recv + un-tile overlap frame k+1's kernels.
@@ -966,6 +1128,13 @@ int rt_gather_gbuffer(RtContext* ctx, void* comm_, int root, void* const* frames
         RT_HIP(ctx, hipStreamWaitEvent(ctx->gather_stream, ctx->ev_ready[s], 0));
         gs = ctx->gather_stream;
         src = ctx->stage[s];
+    }
+    // RT_FLAG_TIMING: events round the transfer + un-tile on the stream they run on (rt_get_gather_timing)
+    size_t gev = (size_t)-1;
+    if ((ctx->cfg.flags & RT_FLAG_TIMING) != 0 && ctx->gather_ev_used + 2 <= 2 * 4096) {
+        while (ctx->gather_ev.size() < ctx->gather_ev_used + 2) { hipEvent_t ev; RT_HIP(ctx, hipEventCreate(&ev)); ctx->gather_ev.push_back(ev); }
+        gev = ctx->gather_ev_used; ctx->gather_ev_used += 2;
+        RT_HIP(ctx, hipEventRecord(ctx->gather_ev[gev], gs));
     }
     // every rank sends its block to the root; the root posts one receive per rank (its own block included).  Each peer uses
     // its own xGMI link into the root, so the transfers run in parallel.
@@ -996,8 +1165,25 @@ int rt_gather_gbuffer(RtContext* ctx, void* comm_, int root, void* const* frames
                                                    ctx->tiles_y, ctx->cfg.width, ctx->cfg.height, (int)kBytesPerPixel[b], gs));
         }
     }
+    if (gev != (size_t)-1) RT_HIP(ctx, hipEventRecord(ctx->gather_ev[gev + 1], gs));
     if (overlapped) { RT_HIP(ctx, hipEventRecord(ctx->ev_free[s], gs)); ctx->ev_free_recorded[s] = true; }
+    else { RT_HIP(ctx, hipEventRecord(ctx->ev_gather, gs)); ctx->gather_recorded = true; }
     ctx->gathers++;
+    return RT_OK;
+}
+
+int rt_get_gather_timing(RtContext* ctx, float* ms_sum, uint32_t* calls) {
+    if (!ctx || !ms_sum || !calls) return RT_ERR_INVALID_ARG;
+    *ms_sum = 0.0f; *calls = 0;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, sync_lanes(ctx));
+    if (ctx->gather_stream) RT_HIP(ctx, hipStreamSynchronize(ctx->gather_stream));
+    for (size_t i = 0; i + 1 < ctx->gather_ev_used; i += 2) {
+        float ms = 0.0f;
+        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->gather_ev[i], ctx->gather_ev[i + 1]));
+        *ms_sum += ms; (*calls)++;
+    }
+    ctx->gather_ev_used = 0;
     return RT_OK;
 }
 
@@ -1037,8 +1223,11 @@ int rt_get_info(RtContext* ctx, RtInfo* out) {
     if (out->struct_size != sizeof(RtInfo)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_get_info: RtInfo.struct_size mismatch");
     out->num_cus = ctx->num_cus;
     out->samples_per_launch = ctx->kernel == RT_KERNEL_PERSISTENT ? ctx->persist_batch : ctx->batch_samples;
+    out->launches_in_flight = (uint16_t)(ctx->user_stream ? 1 : ctx->nlanes);
+    out->frames_in_flight = (uint16_t)(ctx->user_stream ? 1 : ctx->nslots);
     out->light_record_budget_bytes = ctx->light_budget_bytes;
-    out->light_record_bytes = ctx->kernel == RT_KERNEL_PERSISTENT ? (uint64_t)sizeof(rtd::PathLight) * (ctx->npix_pad ? ctx->npix_pad : 1) * ctx->persist_batch : 0;
+    out->light_record_bytes = ctx->kernel == RT_KERNEL_PERSISTENT
+        ? (uint64_t)sizeof(rtd::PathLight) * (ctx->npix_pad ? ctx->npix_pad : 1) * ctx->persist_batch * (uint64_t)ctx->nlanes : 0;
     out->device_bytes = ctx->device_bytes;
     return RT_OK;
 }
@@ -1047,14 +1236,13 @@ int rt_kernel_in_use(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->last_path_kernel != 0) return ctx->last_path_kernel;   // what the last frame ran
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 3) return RT_KERNEL_PATHS;
-    if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 4) return RT_KERNEL_SEQ;
     return ctx->kernel;
 }
 
 int rt_get_counters(RtContext* ctx, RtCounters* out) {
     if (!ctx || !out) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, sync_lanes(ctx));
     rtd::DevCounters d;
     RT_HIP(ctx, hipMemcpy(&d, ctx->d_counters, sizeof(d), hipMemcpyDeviceToHost));
     out->rays = d.rays; out->rays_primary = d.rays_primary; out->rays_shadow = d.rays_shadow; out->rays_diffuse = d.rays_diffuse;
@@ -1062,6 +1250,13 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     out->noise_fetches = d.noise_fetches + ctx->host_noise_base;   // + the seed-base texel of each sample (raytrace.comp:302-303)
     out->hits = d.hits; out->sky_exits = d.sky_exits; out->limit_exits = d.limit_exits; out->border_fetches = d.border_fetches;
     out->pixels = d.pixels; out->frames = ctx->host_frames;
+    if (const char* path = getenv("RT_DEBUG_WAVE_DUMP")) {   // -DRT_DIAG_WAVE_TIMES builds of k_paths: per-wave (start, out of paths, end, workgroup)
+        if (ctx->lanes[0].pstack) {
+            std::vector<unsigned long long> rec((size_t)ctx->num_cus * 16u * 4u);
+            if (hipMemcpy(rec.data(), ctx->lanes[0].pstack, rec.size() * sizeof(rec[0]), hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE* fp = fopen(path, "wb")) { fwrite(rec.data(), sizeof(rec[0]), rec.size(), fp); fclose(fp); }
+        }
+    }
     if (getenv("RT_DEBUG_STATS"))
         fprintf(stderr, "[rt] wave loop iters %llu | S block execs %llu (avg lanes %.1f) | F block execs %llu (avg lanes %.1f) | passes %llu "
                         "(avg lanes %.1f, sky lanes %.1f)\n", d.dbg_loop_iters, d.dbg_s_execs, d.dbg_s_execs ? (double)d.dbg_s_lanes / d.dbg_s_execs : 0.0,
@@ -1076,7 +1271,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
 int rt_reset_counters(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, sync_lanes(ctx));
     RT_HIP(ctx, hipMemset(ctx->d_counters, 0, sizeof(rtd::DevCounters)));
     ctx->host_noise_base = 0; ctx->host_frames = 0;
     return RT_OK;
@@ -1087,7 +1282,7 @@ int rt_get_timing(RtContext* ctx, RtTiming* out) {
     memset(out, 0, sizeof(*out));
     if (!ctx->frame_recorded) return fail(ctx, RT_ERR_NOT_READY, "rt_get_timing: no frame drawn yet");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, sync_lanes(ctx));
     if ((ctx->cfg.flags & RT_FLAG_TIMING_ALL) == RT_FLAG_TIMING_ALL)   // 0 for a context created without RT_FLAG_TIMING_ALL
         RT_HIP(ctx, hipEventElapsedTime(&out->frame_ms, ctx->ev_frame0, ctx->ev_frame1));
     // per-launch events accumulate over every frame drawn since the previous rt_get_timing (no per-frame sync needed)

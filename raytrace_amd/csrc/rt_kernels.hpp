@@ -52,8 +52,10 @@ struct PrimaryArgs {
                                 // face id << 28 | gl_WorkGroupID.y * 8 << 14 | gl_WorkGroupID.x * 8 (the noise_offset terms, raytrace.comp:304)
     uint32_t* worklist;         // local pixel ids that need shadow/diffuse rays
     uint32_t* wl_count;         // zero before launch
-    uint32_t* zero_words;       // k_primary2: words the prepass clears for the NEXT frame (its cursor set, idle during this one), or null
-    uint32_t zero_count;
+    uint32_t* zero_words;       // k_primary2: words the prepass clears for later launches instead of a memset of their own: the slot's other
+    uint32_t zero_count;        // worklist counter (the slot's next frame) ...
+    uint32_t* zero_words2;      // ... and the path cursors of the lane this frame's first path launch runs on; either may be null
+    uint32_t zero_count2;
     float4* acc;                // (unused by the prepass since it stores the lighting of the pixels it finishes itself)
     DevCounters* counters;
 };
@@ -68,7 +70,7 @@ struct PersistArgs {
     uint32_t npix_pad;          // CACHE=false: nwork = all local pixels (padded to whole 8x8 tiles)
     uint32_t sample0, nsamples; // samples of this batch: sample0 .. sample0+nsamples-1
     uint32_t threshold;         // parked lanes per wave that trigger a transition pass (1..64)
-    uint32_t rmin;              // k_seq: contexts waiting for their diffuse ray that trigger the in-loop re-arm block
+    uint32_t rmin;              // (was k_seq's re-arm threshold; unused)
     uint32_t chunk;             // paths per cursor atomic; 0 = the default (128)
     uint32_t nthreads;          // grid size in threads (stride of the albedo stack)
     uint32_t direct;            // 1: the frame has ONE sample, so a path's light is its pixel's: the kernel stores the lighting planes
@@ -98,10 +100,6 @@ hipError_t launch_persist(const Scene& sc, const Frame& f, const Planes& pl, con
 bool launch_paths_direct_ok(const Frame& f);   // does k_paths honour PersistArgs::direct for this frame?
 hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nworkgroups,
                         hipStream_t st);
-
-// k_seq (rt_seq.hip): nc = paths per lane (2 or 3); same coverage as k_paths
-hipError_t launch_seq(const Scene& sc, const Frame& f, const Planes& pl, const PersistArgs& a, bool count, int nc, int nworkgroups,
-                      hipStream_t st);
 
 hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
                           uint32_t* coarse, uint32_t* bad_flag, int logr, hipStream_t st);

@@ -561,6 +561,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             atomicAdd(&cn->dbg_passes, 1ull);                          // waves
             atomicAdd(&cn->dbg_pass_lanes, t1 & 0xFFFFFFFFFFull);      // sum of the end times (40 bits each)
             atomicAdd(&cn->dbg_f_lanes, (t_exh ? t_exh : t1) & 0xFFFFFFFFFFull);   // sum of the exhaustion times
+            if (STK == 0) {   // per-wave record in the (otherwise unused) global stack: start, out of paths, end (RT_DEBUG_WAVE_DUMP, tools/lab/r4/wg_end_times.py)
+                unsigned long long* rec = reinterpret_cast<unsigned long long*>(a.stack) + (size_t)(gtid >> 6) * 4u;
+                rec[0] = t_wave0; rec[1] = t_exh; rec[2] = t1; rec[3] = blockIdx.x;
+            }
 #endif
         }
     }

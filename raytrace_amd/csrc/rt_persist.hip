@@ -140,10 +140,13 @@ __global__ __launch_bounds__(1024) void k_primary2(Scene sc, Frame f, Planes pl,
     __shared__ uint32_t s_coarse[kCoarseWords];
     __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];
     __shared__ uint32_t s_cnt[16], s_off[17];   // worklist append: pixels queued by each wave this round, their slot offsets
-    // the cursor set of the NEXT frame (path cursors + worklist count; idle during this frame) is cleared here instead of by a
-    // memset of its own in front of every frame (two fill kernels, 9 us of a 230 us frame at 1024^2)
-    if (a.zero_words != nullptr && blockIdx.x == 0u)
-        for (uint32_t i = threadIdx.x; i < a.zero_count; i += 1024u) a.zero_words[i] = 0u;
+    // what later launches need zeroed — the frame slot's other worklist counter (the slot's next frame) and the path cursors of
+    // the lane this frame's first path launch runs on (idle until then) — is cleared here instead of by memsets of their own in
+    // front of every frame (two fill kernels, 9 us of a 230 us frame at 1024^2)
+    if (blockIdx.x == 0u) {
+        if (a.zero_words != nullptr) for (uint32_t i = threadIdx.x; i < a.zero_count; i += 1024u) a.zero_words[i] = 0u;
+        if (a.zero_words2 != nullptr) for (uint32_t i = threadIdx.x; i < a.zero_count2; i += 1024u) a.zero_words2[i] = 0u;
+    }
     {
         const uint4* src = reinterpret_cast<const uint4*>(sc.coarse);
         uint4* dst = reinterpret_cast<uint4*>(s_coarse);

@@ -220,6 +220,7 @@ void rth_pipeline_set_seed(void* p, uint32_t seed) { static_cast<render::Pipelin
 void rth_pipeline_enable_streaming(void* p, uint64_t seed, const char* dir) {
     static_cast<render::Pipeline*>(p)->enable_terrain_streaming(seed, dir ? dir : "");
 }
+int rth_pipeline_enable_post_passes(void* p, int faithful) { return static_cast<render::Pipeline*>(p)->enable_post_passes(faithful != 0); }
 const char* rth_pipeline_last_error(void* p) { return static_cast<render::Pipeline*>(p)->last_error(); }
 
 }  // extern "C"

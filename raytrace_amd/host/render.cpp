@@ -46,6 +46,7 @@ Pipeline* create_instance(const RtConfig& cfg, const uint8_t* blue_noise_rgba8, 
     p->ctx_ = ctx;
     p->spp_ = cfg.spp > 0 ? cfg.spp : 1;
     p->region_ = cfg.region;
+    p->tile_world_ = cfg.tile_world;
     std::memset(&p->uniforms_, 0, sizeof(p->uniforms_));
     p->uniforms_.lr[0] = -64; p->uniforms_.lr[1] = -64;    // create_raytrace_uniform_data, render_data.rs:146-147;
     p->uniforms_.lso[0] = -64; p->uniforms_.lso[1] = -64;  // overwritten on the first draw_frame (pipeline.rs:203-207)
@@ -57,6 +58,13 @@ Pipeline::~Pipeline() { rt_destroy(ctx_); }
 void Pipeline::enable_terrain_streaming(uint64_t seed, const std::string& storage_dir) {
     chunks_.reset(new world::ChunkStorage(storage_dir, seed));
     tum_.reset(new TerrainUploadManager(region_));
+}
+
+int Pipeline::enable_post_passes(bool faithful) {
+    if (tile_world_ != 1) return RT_ERR_UNIMPLEMENTED;   // a 48-pixel halo is needed: gather the tiles, then rt_denoise_planes / rt_finalize_planes
+    post_ = true;
+    post_faithful_ = faithful;
+    return RT_OK;
 }
 
 const char* Pipeline::last_error() const { return rt_last_error(ctx_); }
@@ -108,7 +116,11 @@ int Pipeline::draw_frame(game::Game& game) {
     }
     u.seed = (u.seed + 1) % (uint32_t)RT_NOISE_BYTES;                // :201
     u.sun_angle = game.get_sun_angle();                              // :202
-    rc = rt_draw_frame(ctx_, &u);                                    // :209-211 + :229-235
+    rc = rt_draw_frame(ctx_, &u);                                    // :209-211; the dispatch recorded at :86-90
+    if (rc == RT_OK && post_) {                                      // the same command buffer goes on (:98-123), one submit (:229-235)
+        rc = rt_denoise(ctx_, post_faithful_ ? 1 : 0);               // six bilateral_denoise.comp dispatches, sizes 1,2,4,8,8,16
+        if (rc == RT_OK) rc = rt_finalize(ctx_);                     // finalize.comp -> the swapchain image
+    }
     // spp > 1 consumes seeds seed..seed+spp-1; leave the counter on the last one used.
     u.seed = (u.seed + (uint32_t)(spp_ - 1)) % (uint32_t)RT_NOISE_BYTES;
     // :213-227 — written after the upload so it only affects the next frame; the shader never reads it (Q9).

@@ -73,6 +73,14 @@ class Pipeline {
     // (static region).  `storage_dir` empty = no disk cache.
     void enable_terrain_streaming(uint64_t seed, const std::string& storage_dir);
     TerrainUploadManager* terrain_upload_manager() { return tum_.get(); }
+    // The rest of the reference's per-frame command buffer (pipeline.rs:98-123): after the ray-trace dispatch, the six
+    // bilateral_denoise.comp dispatches and finalize.comp, submitted together (:229-235).  When enabled, draw_frame enqueues
+    // ray trace -> rt_denoise -> rt_finalize on the context's stream and RT_BUF_FINAL_BGRA8 holds the swapchain image of the
+    // frame.  `faithful` = the reference's pong descriptor set with its swapped bindings (descriptor_sets.rs:38-39).
+    // Off by default (the G-buffer planes are then the ray-trace dispatch's own output, which the parity tests compare);
+    // whole-frame contexts only (RT_ERR_UNIMPLEMENTED on a tile-split one: the passes need a halo, gather first).
+    int enable_post_passes(bool faithful);
+    bool post_passes() const { return post_; }
 
  private:
     friend Pipeline* create_instance(const RtConfig&, const uint8_t*, game::Game&, std::string*);
@@ -82,6 +90,8 @@ class Pipeline {
     int spp_ = 1;
     int region_ = RT_ROOT_BLOCK_SIZE;
     int render_offset_[3] = {0, 0, 0}; // TerrainUploadManager::get_render_offset (terrain_upload.rs:30-47)
+    int tile_world_ = 1;
+    bool post_ = false, post_faithful_ = true;
     std::unique_ptr<TerrainUploadManager> tum_;
     std::unique_ptr<world::ChunkStorage> chunks_;
 };

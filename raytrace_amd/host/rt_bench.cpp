@@ -5,7 +5,10 @@
 // asks of the bench binary (config, rays, ms, Mrays/s).
 //
 //   rt_bench [x y z heading pitch sun] [--width W] [--height H] [--spp N] [--depth D] [--frames F]
-//            [--noise tests/golden/blue_noise_512.rgba] [--device I] [--gpus N] [--gather] [--overlap]
+//            [--noise tests/golden/blue_noise_512.rgba] [--device I] [--gpus N] [--gather] [--overlap] [--post]
+//
+// --post: the reference's whole frame — ray trace, six denoise dispatches, finalize (pipeline.rs:86-123) — per draw_frame
+// (Pipeline::enable_post_passes; one device only: the passes need the whole frame).
 //
 // --gpus N (one host thread per device, ncclCommInitAll through rt_comm_init_all): device i renders the tiles t % N == i and
 // every frame ends with rt_gather_gbuffer to device 0, which assembles the full frame in the library's own planes.
@@ -82,7 +85,7 @@ class ThreadBarrier {
 int main(int argc, char** argv) {
     int width = 1024, height = 1024;   // WINDOW_WIDTH / WINDOW_HEIGHT, src/render/constants.rs:9-10
     int spp = 1, depth = 2, frames = 240, device = 0, gpus = 1;
-    bool gather = false, overlap = false;
+    bool gather = false, overlap = false, post = false;
     std::string noise_path = "tests/golden/blue_noise_512.rgba";
     std::vector<const char*> positional = {argv[0]};
     for (int i = 1; i < argc; i++) {
@@ -97,10 +100,12 @@ int main(int argc, char** argv) {
         else if (want("--noise")) noise_path = argv[++i];
         else if (std::strcmp(argv[i], "--gather") == 0) gather = true;
         else if (std::strcmp(argv[i], "--overlap") == 0) overlap = true;
+        else if (std::strcmp(argv[i], "--post") == 0) post = true;
         else positional.push_back(argv[i]);
     }
     if (gpus < 1 || frames < 1) { std::fprintf(stderr, "--gpus and --frames must be >= 1\n"); return 2; }
     if (gpus > 1) gather = true;
+    if (post && gpus > 1) { std::fprintf(stderr, "--post needs the whole frame on one device (gather first on several)\n"); return 2; }
     rt::game::Game game((int)positional.size(), positional.data());
 
     std::vector<uint8_t> noise(RT_NOISE_BYTES);
@@ -144,6 +149,7 @@ int main(int argc, char** argv) {
             return 1;
         }
     }
+    if (post && pipes[0]->enable_post_passes(true) != RT_OK) { std::fprintf(stderr, "enable_post_passes failed\n"); return 1; }
     if (gather) {
         int rc = rt_comm_init_all(gpus, devices.data(), comms.data());
         if (rc != RT_OK) { std::fprintf(stderr, "rt_comm_init_all failed (%d): %s\n", rc, rt_last_error(nullptr)); return 1; }
@@ -209,14 +215,21 @@ int main(int argc, char** argv) {
                 for (uint16_t v : depth_plane) checksum += v;
             else { std::fprintf(stderr, "rt_frame_readback failed: %s\n", pipes[0]->last_error()); exit_code = 1; }
         }
+        unsigned long long final_checksum = 0;   // --post: sum over the swapchain image's bytes (0 without)
+        if (post) {
+            std::vector<uint8_t> final_plane((size_t)width * height * 4);
+            if (rt_readback(pipes[0]->context(), RT_BUF_FINAL_BGRA8, final_plane.data(), final_plane.size()) == RT_OK)
+                for (uint8_t v : final_plane) final_checksum += v;
+            else { std::fprintf(stderr, "rt_readback(final) failed: %s\n", pipes[0]->last_error()); exit_code = 1; }
+        }
         const double ms = total_ms / frames;
         std::printf("{\"binary\": \"rt_bench\", \"config\": {\"width\": %d, \"height\": %d, \"spp\": %d, \"depth\": %d, \"gpus\": %d, "
-                    "\"gather\": \"%s\", \"pose\": [%g, %g, %g, %g, %g], \"sun_angle\": %g}, \"frames\": %d, \"rays_per_frame\": %llu, "
+                    "\"gather\": \"%s\", \"post_passes\": %s, \"pose\": [%g, %g, %g, %g, %g], \"sun_angle\": %g}, \"frames\": %d, \"rays_per_frame\": %llu, "
                     "\"ms_per_frame\": %.4f, \"avg_ms_last_120\": %.4f, \"max_ms_last_120\": %.4f, \"mrays_per_s\": %.2f, "
-                    "\"depth_plane_checksum\": %llu}\n",
-                    width, height, spp, depth, gpus, gather ? (overlap ? "rccl-overlapped" : "rccl-serial") : "none",
+                    "\"depth_plane_checksum\": %llu, \"final_image_checksum\": %llu}\n",
+                    width, height, spp, depth, gpus, gather ? (overlap ? "rccl-overlapped" : "rccl-serial") : "none", post ? "true" : "false",
                     game.camera.origin[0], game.camera.origin[1], game.camera.origin[2], game.camera.heading, game.camera.pitch,
-                    game.sun_angle, frames, rays_per_frame, ms, perf.average(), perf.max(), (double)rays_per_frame / (ms * 1e3), checksum);
+                    game.sun_angle, frames, rays_per_frame, ms, perf.average(), perf.max(), (double)rays_per_frame / (ms * 1e3), checksum, final_checksum);
     }
     for (int g = 0; g < gpus; g++) {
         if (comms[(size_t)g]) rt_comm_destroy(comms[(size_t)g]);

@@ -242,6 +242,13 @@ class Context:
         self._check(self._lib.rt_get_timing(self._h, C.byref(t)))
         return t
 
+    def gather_timing(self):
+        """rt_get_gather_timing: (sum of the rt_gather_gbuffer calls' device time in ms, number of calls) since the last call —
+        events round the transfer + un-tile on the stream they run on; contexts with RT_FLAG_TIMING only (else (0.0, 0))."""
+        ms, n = C.c_float(0.0), C.c_uint32(0)
+        self._check(self._lib.rt_get_gather_timing(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
 
 # ---- host mirror of the reference API ------------------------------------------------------------------------
 
@@ -367,6 +374,13 @@ class Pipeline:
     def enable_terrain_streaming(self, seed=0x5EED, storage_dir=""):
         """pipeline.rs:174-189: every draw_frame moves the TerrainUploadManager towards the camera (<= 1 slab per frame)."""
         _lib.host().rth_pipeline_enable_streaming(self._h, C.c_uint64(int(seed)), str(storage_dir).encode() if storage_dir else None)
+
+    def enable_post_passes(self, faithful=True):
+        """pipeline.rs:98-123: every draw_frame then enqueues ray trace -> six denoise dispatches -> finalize (the reference's one
+        command buffer, :229-235); RT_BUF_FINAL_BGRA8 holds the frame's swapchain image.  Whole-frame contexts only."""
+        rc = _lib.host().rth_pipeline_enable_post_passes(self._h, 1 if faithful else 0)
+        if rc != 0:
+            raise RtError(rc, "enable_post_passes: whole-frame contexts only (tile_world == 1)")
 
     def close(self):
         if self._h:

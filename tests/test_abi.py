@@ -28,6 +28,36 @@ def test_library_exports_every_declared_symbol():
     assert lib.rt_abi_version() >> 16 == 1
 
 
+def test_abi_minor_version_is_pinned_and_its_history_is_in_the_header():
+    """the ABI changed in round 3 (new exports, RtKernel 4 rejected, asynchronous rt_upload_slice) without a version
+    bump.  The minor version now moves with every such change and the header says which minor introduced what."""
+    lib = _lib.amd()
+    text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+    major = int(re.search(r"#define RT_ABI_VERSION_MAJOR (\d+)", text).group(1))
+    minor = int(re.search(r"#define RT_ABI_VERSION_MINOR (\d+)", text).group(1))
+    assert (major, minor) == (1, 2)
+    assert lib.rt_abi_version() == (major << 16) | minor
+    for needle in ("1.1  round 3: rt_slice_staging", "1.2  round 4: RT_FLAG_FRAMES_IN_FLIGHT_2", "rt_samples_per_launch", "rt_get_gather_timing"):
+        assert needle in text, needle
+    assert abi.RT_FLAG_FRAMES_IN_FLIGHT_2 == int(re.search(r"#define RT_FLAG_FRAMES_IN_FLIGHT_2 (0x[0-9a-f]+)u", text).group(1), 16)
+    assert C.sizeof(abi.RtInfo) == 40 and abi.RtInfo.launches_in_flight.offset == 12 and abi.RtInfo.frames_in_flight.offset == 14
+
+
+def test_launch_sizing_rule():
+    """the samples one path launch covers (free memory, pixels, spp -> B) as a pure function of its inputs."""
+    f = _lib.amd().rt_samples_per_launch
+    GiB = 1 << 30
+    npix_1080, npix_4k = 1920 * 1080, 3840 * 2160
+    assert f(8 * GiB, npix_1080, 64, None) == 64                       # the headline frame: one launch per frame on either lane
+    assert f(8 * GiB, npix_4k, 256, None) == 8 * GiB // (12 * npix_4k) == 86      # C4: 86 + 86 + 84 samples over two lanes
+    assert f(1 * GiB, npix_4k, 256, None) == 10
+    assert f(100, npix_4k, 256, None) == 1                             # never below one sample
+    assert f(64 * GiB, npix_4k, 1024, None) == (1 << 31) // npix_4k    # path indices are 32-bit
+    assert f(8 * GiB, 0, 4, None) == 4                                 # an empty share still sizes
+    assert f(8 * GiB, npix_4k, 256, b"16") == 16                       # RT_PERSIST_BATCH lowers ...
+    assert f(8 * GiB, npix_4k, 256, b"500") == 86                      # ... and never raises the bound
+
+
 def test_uniform_block_layout_matches_the_reference():
     # src/render/pipeline/structs.rs:3-31; shaders/glsl/raytrace.comp:25-35 (std140)
     assert C.sizeof(abi.RtUniforms) == 192
@@ -56,7 +86,7 @@ def test_create_rejects_bad_configs_before_touching_a_device():
     assert lib.rt_create(C.byref(cfg), C.byref(h)) == abi.RT_ERR_INVALID_ARG and not h
     assert b"struct_size" in lib.rt_last_error(None)
     for bad in (dict(width=0), dict(height=-3), dict(spp=0), dict(depth=17), dict(tile_rank=2, tile_world=2),
-                dict(kernel=9), dict(region=128)):
+                dict(kernel=9), dict(kernel=4), dict(kernel=6), dict(region=128)):
         cfg = render.make_config(64, 64)
         for k, v in bad.items():
             setattr(cfg, k, v)

@@ -59,7 +59,7 @@ def test_gpu_reproduces_golden(case, kernel, scenes_cache, blue_noise):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PATHS, abi.RT_KERNEL_SEQ])
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PATHS])
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_gpu_paths_kernel_reproduces_golden(case, kernel, scenes_cache, blue_noise):
     """RT_KERNEL_PATHS (cached primaries: the configuration RT_KERNEL_DEFAULT runs) on the golden frames; frames with lr != 0

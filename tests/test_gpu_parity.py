@@ -63,7 +63,7 @@ def _cached_counters(mats, mine, noise, u, W, H, spp, depth, ccn, **kw):
     return d
 
 
-PATH_KERNELS = [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PATHS, abi.RT_KERNEL_SEQ]
+PATH_KERNELS = [abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_PATHS]
 
 CASES = [
     # W, H, spp, depth
@@ -1083,22 +1083,7 @@ def test_rt_bench_binary_runs_and_reports_metrics(native_built):
     assert lines["gather"]["rays_per_frame"] == lines["plain"]["rays_per_frame"]
 
 
-@pytest.mark.parametrize("nc", ["2", "3"])
-def test_seq_kernel_with_two_and_three_paths_per_lane(procedural_region, blue_noise, nc, monkeypatch):
-    """RT_KERNEL_SEQ carries RT_SEQ_NC paths per lane (one ray slot each): both instantiations, planes and the exact counters of
-    the cached-primary frame, at depths on both sides of the LDS / global albedo-stack boundary."""
-    monkeypatch.setenv("RT_SEQ_NC", nc)
-    mats, mine = procedural_region
-    u = _uniforms(seed=31)
-    for W, H, spp, depth in ((104, 56, 3, 4), (72, 40, 2, 7)):
-        cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
-        gpu, gcn = _render_gpu(mats, mine, blue_noise, u, W, H, spp, depth, abi.RT_KERNEL_SEQ,
-                               flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS)
-        _compare(gpu, cpu)
-        assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, spp, depth, ccn)
-
-
-@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PATHS, abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_SEQ])
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PATHS, abi.RT_KERNEL_PERSISTENT])
 @pytest.mark.parametrize("origin,special", [((-200.0, 10.0, 30.0), True), ((-200.0, 10.0, 124.0), False), ((60.0, 300.0, 20.0), True)])
 def test_cameras_outside_the_region(procedural_region, blue_noise, kernel, origin, special):
     """The region texture wraps (mod(p + 128, 256), raytrace.comp:137), so a camera outside it fetches the texel on the far side:

@@ -2,7 +2,7 @@
 # Quick GPU visit: the parity tests that exercise the default path kernel, then the headline bench (HIP-event time per launch).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_golden.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py -m gpu -x -q -k "paths or PATHS or seq or SEQ or edge or scheduling or fuzz or random or batches or tile_split or primary_cache or tables" > gpurun_out/pytest_quick.log 2>&1; rc=$?
+timeout -k 10 600 python -m pytest tests/test_golden.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py -m gpu -x -q -k "paths or PATHS or edge or scheduling or fuzz or random or batches or tile_split or primary_cache or tables" > gpurun_out/pytest_quick.log 2>&1; rc=$?
 tail -3 gpurun_out/pytest_quick.log
 [ $rc -ne 0 ] && exit $rc
 for extra in "$@"; do

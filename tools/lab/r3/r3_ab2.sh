@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of two libraries on headline / C4 / C5: tools/r3_ab2.sh libA.so libB.so [tag]
+# same-box A/B of two libraries on headline / C4 / C5: tools/lab/r3/r3_ab2.sh libA.so libB.so [tag]
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 A=$1; B=$2; TAG=${3:-ab2}
