@@ -56,6 +56,9 @@ def parse_args():
                     help="render offset of a scrolled region (multiples of 16 voxels, terrain_upload.rs:84-275): the scene is the "
                          "toroidal window around it and the camera moves with it — what every frame looks like once the camera has "
                          "travelled; region 256 only")
+    ap.add_argument("--pose", default=None, metavar="X,Y,Z,HEADING,PITCH",
+                    help="camera pose in the region's own coordinates instead of the reference's default pose scaled with the region "
+                         "(e.g. the terrain-heavy C5 pose -120,-512,160,1.5707964,-0.3: tools/bench_configs.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
                     help="2 (default): RT_FLAG_FRAMES_IN_FLIGHT_2 — the K frames are enqueued back to back and frame k+1 starts on the CUs "
@@ -193,6 +196,9 @@ def main():
     pose = dict(render.DEFAULT_POSE)
     scale = REGION // 256            # C5 pose (-120,-512,400) = the default pose scaled with the region
     pose["origin"] = tuple(c * scale + o for c, o in zip(pose["origin"], LR))
+    if args.pose:
+        pv = [float(v) for v in args.pose.split(",")]
+        pose["origin"], pose["heading"], pose["pitch"] = tuple(pv[:3]), pv[3], pv[4]
 
     def uniforms(seed):
         return render.camera_uniforms(pose["origin"], pose["heading"], pose["pitch"], pose["sun_angle"], seed=seed, lr=LR)
@@ -459,8 +465,9 @@ def main():
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d spp=%d depth=%d, procedural %d^3 region seed 0x5EED, pose (%g,%g,%g) h=pi/2 p=0 sun=0"
-                                   % ((W, H, SPP, D, REGION) + tuple(pose["origin"])), "kernel": rec["kernel"],
+            "config": {"workload": "%dx%d spp=%d depth=%d, procedural %d^3 region seed 0x5EED, pose (%g,%g,%g) h=%s p=%g sun=0"
+                                   % ((W, H, SPP, D, REGION) + tuple(pose["origin"]) + ("pi/2" if not args.pose else "%g" % pose["heading"], pose["pitch"])),
+                       "kernel": rec["kernel"],
                        "rays_per_frame": int(rec["rays_total"]), "reference_equivalent_rays_per_frame": int(rec["ref_rays_total"]),
                        "algorithmic_bytes_per_frame": int(rec["balg_total"]), "parallelism": "tiles%d" % world, **({"share_of": args.share_of} if args.share_of else {}),
                        "primary_cache": bool(args.cache_primary), "lr": list(LR), "frame_sha256_16": rec["sha"],

@@ -236,17 +236,21 @@ int rt_upload_world(RtContext* ctx, const uint32_t* materials, const uint8_t* mi
  * launch over its 16 R^2 voxels + the nibble-map words it touches); any region size.
  * Asynchronous: the slab is copied into pinned staging (the host's buffers are free again at return), transferred on the
  * library's upload stream and applied on the context's stream after the frames already submitted — the call does not wait
- * for them (the reference does: vkQueueWaitIdle, pipeline.rs:181-189).  Without RT_FLAG_TRUSTED_WORLD the minefield
+ * for them (the reference does: vkQueueWaitIdle, pipeline.rs:181-189).  There are two staging sets, used in turn: the call
+ * waits (on the host) only until the slab BEFORE LAST has left its pinned buffer, and that slab's transfer waited only for the
+ * re-tile of the one two before it — a host that uploads one slab per frame with one or two frames in flight never waits for
+ * a frame; three slabs back to back behind a long frame do wait for it.  Without RT_FLAG_TRUSTED_WORLD the minefield
  * is checked first, on the host (values above 30 -> RT_ERR_INVALID_ARG); a rejected slab is NOT applied: the region and
  * what can be drawn stay as they were. */
 int rt_upload_slice(RtContext* ctx, int axis, int texel_offset,
                     const uint32_t* materials, const uint8_t* minefield);
 
 /* The upload buffers of TerrainUploadManager::new (terrain_upload.rs:65-82) are host-visible mapped Vulkan buffers the CPU
- * fills in place; this is their counterpart: pinned host memory for ONE slab (u32[16 R^2] materials, u8[16 R^2] minefield).
- * A host that assembles its slab there and hands these very pointers to rt_upload_slice saves the copy into the staging
- * buffer.  The memory is the host's to write from the return of this call until its next rt_upload_slice (the call waits
- * until the previous slab's transfer has left the buffer); it lives as long as the context. */
+ * fills in place; this is their counterpart: pinned host memory for ONE slab (u32[16 R^2] materials, u8[16 R^2] minefield) —
+ * the staging set the NEXT rt_upload_slice will use (there are two, used in turn, so the pointers alternate from slab to slab:
+ * ask again for every slab).  A host that assembles its slab there and hands these very pointers to rt_upload_slice saves the
+ * copy into the staging buffer.  The memory is the host's to write from the return of this call until that rt_upload_slice
+ * (the call waits until the slab before last has left the buffer); it must not be touched afterwards and is freed by rt_destroy. */
 int rt_slice_staging(RtContext* ctx, uint32_t** materials, uint8_t** minefield);
 
 /* Allocation figures of the context (see RtInfo). */

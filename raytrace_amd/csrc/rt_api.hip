@@ -35,13 +35,6 @@ constexpr uint64_t kPathsCrossover = 3ull << 20;
 // light records of one launch above which k_paths streams them out and k_accumulate_paths streams them in (see rt_draw_frame)
 constexpr uint64_t kStreamRecordBytes = 384ull << 20;
 
-// Round 4 — two launches in flight.  A persistent path launch ends in a drain: its workgroups finish 0.1-0.25 ms
-// apart and each holds its CU (all 512 VGPRs of every SIMD, 158 KiB of LDS) until its last wave has ended, so the next launch on
-// the same stream finds the GPU half empty for that long (profiles/r4_wg_end_times.txt).  The library therefore alternates its
-// path launches between two LANES — a stream with everything a launch writes while it runs: cursors, albedo stack, light
-// records — so that the workgroups of launch n + 1 take the CUs launch n's workgroups leave: the sample batches of one frame
-// (always), and with RT_FLAG_FRAMES_IN_FLIGHT_2 the frames themselves, which then render into two FRAME SLOTS (G-buffer planes,
-// worklist, primary hits, per-pixel sums) used in turn.  Ordering is by events on the device; the host waits for nothing.
 struct Lane {
     hipStream_t stream = nullptr;      // lane 0: the context's stream (its own or the caller's, rt_set_stream); lane 1: the library's second stream
     uint32_t* cursor = nullptr;        // kCursorWords: eight path cursors, one 128-byte line each
@@ -83,12 +76,16 @@ struct RtContext {
     // (the caller-layout copy of the region exists only inside rt_upload_world: 5 B/voxel, 5 GiB at R = 1024)
     uint8_t* d_mine_sw = nullptr; uint32_t* d_mat_sw = nullptr;
     uint32_t* d_coarse = nullptr; uint32_t* d_noise = nullptr; uint32_t* d_flag = nullptr;
-    // rt_upload_slice: one 16-thick slab travels pinned host staging -> device staging (own stream) -> re-tile (render stream)
-    uint8_t* d_slab_mine = nullptr; uint32_t* d_slab_mat = nullptr;
-    uint8_t* h_slab_mine = nullptr; uint32_t* h_slab_mat = nullptr;   // hipHostMalloc
+    uint32_t* d_brick = nullptr;          // R > 256: per-brick nibble map (rtd::Scene::brick), R^3 / 128 bytes
+    // rt_upload_slice: a 16-thick slab travels pinned host staging -> device staging (own stream) -> re-tile (render stream).
+    // TWO staging sets used in turn: slab n's transfer waits for slab n - 2's re-tile, not for slab n - 1's, which sits
+    // behind the frames on the render stream — a host that uploads one slab per frame never waits for a frame
+    uint8_t* d_slab_mine[2] = {nullptr, nullptr}; uint32_t* d_slab_mat[2] = {nullptr, nullptr};
+    uint8_t* h_slab_mine[2] = {nullptr, nullptr}; uint32_t* h_slab_mat[2] = {nullptr, nullptr};   // hipHostMalloc
+    uint64_t slabs = 0;                   // slabs submitted: the next one uses set slabs & 1
     hipStream_t upload_stream = nullptr;
-    hipEvent_t ev_slab_copied = nullptr, ev_slab_applied = nullptr;   // host staging read / device staging consumed
-    bool slab_copy_pending = false, slab_apply_recorded = false;
+    hipEvent_t ev_slab_copied[2] = {nullptr, nullptr}, ev_slab_applied[2] = {nullptr, nullptr};   // per set: host staging read / device staging consumed
+    bool slab_copy_pending[2] = {false, false}, slab_apply_recorded[2] = {false, false};
 
     // tiling
     int tiles_x = 0, tiles_y = 0, ntiles_total = 0, ntiles_local = 0, tile_capacity = 0;
@@ -197,6 +194,7 @@ hipError_t dev_alloc(RtContext* c, T** p, size_t count) {
 rtd::Scene scene_of(const RtContext* c) {
     rtd::Scene s;
     s.mine = c->d_mine_sw; s.mat = c->d_mat_sw; s.coarse = c->d_coarse; s.noise = c->d_noise;
+    s.brick = c->d_brick ? reinterpret_cast<const uint8_t*>(c->d_brick) : reinterpret_cast<const uint8_t*>(c->d_coarse);
     return s;
 }
 
@@ -300,7 +298,7 @@ hipError_t sync_lanes(RtContext* c) {
 
 int reflatten(RtContext* c, const uint8_t* d_mine_lin, const uint32_t* d_mat_lin) {
     RT_HIP(c, hipMemsetAsync(c->d_flag, 0, sizeof(uint32_t), c->stream));
-    RT_HIP(c, rtd::launch_flatten(d_mine_lin, d_mat_lin, c->d_mine_sw, c->d_mat_sw, c->d_coarse, c->d_flag, c->logr, c->stream));
+    RT_HIP(c, rtd::launch_flatten(d_mine_lin, d_mat_lin, c->d_mine_sw, c->d_mat_sw, c->d_coarse, c->d_brick, c->d_flag, c->logr, c->stream));
     uint32_t flag = 0;
     RT_HIP(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -451,6 +449,8 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     // scene
     RT_HIP_CREATE(dev_alloc(c, &c->d_mine_sw, c->vox)); RT_HIP_CREATE(dev_alloc(c, &c->d_mat_sw, c->vox));
     RT_HIP_CREATE(dev_alloc(c, &c->d_coarse, (size_t)rtd::kCoarseWords));
+    // (the per-brick map of a -DRT_PATHS_BRICK_MAP=1 build of k_paths: an experiment that lost, profiles/r4_c5_brick_map.txt)
+    if (c->logr > 8 && getenv("RT_BRICK_MAP")) RT_HIP_CREATE(dev_alloc(c, &c->d_brick, c->vox / 128u / 4u));
     RT_HIP_CREATE(dev_alloc(c, &c->d_noise, (size_t)RT_NOISE_SIZE * RT_NOISE_SIZE));
     RT_HIP_CREATE(dev_alloc(c, &c->d_flag, 4));
     RT_HIP_CREATE(dev_alloc(c, &c->d_counters, 1));
@@ -590,10 +590,12 @@ void rt_destroy(RtContext* ctx) {
     for (FrameSlot& fs : ctx->slots) for (hipEvent_t e : {fs.ev_prepass, fs.ev_acc, fs.ev_tail}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {ctx->ev_fence, ctx->ev_gather}) if (e) (void)hipEventDestroy(e);
     if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
-    if (ctx->ev_slab_copied) (void)hipEventDestroy(ctx->ev_slab_copied);
-    if (ctx->ev_slab_applied) (void)hipEventDestroy(ctx->ev_slab_applied);
-    if (ctx->h_slab_mat) (void)hipHostFree(ctx->h_slab_mat);
-    if (ctx->h_slab_mine) (void)hipHostFree(ctx->h_slab_mine);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->ev_slab_copied[k]) (void)hipEventDestroy(ctx->ev_slab_copied[k]);
+        if (ctx->ev_slab_applied[k]) (void)hipEventDestroy(ctx->ev_slab_applied[k]);
+        if (ctx->h_slab_mat[k]) (void)hipHostFree(ctx->h_slab_mat[k]);
+        if (ctx->h_slab_mine[k]) (void)hipHostFree(ctx->h_slab_mine[k]);
+    }
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->gather_ev) (void)hipEventDestroy(e);
@@ -651,13 +653,15 @@ namespace {
 // host-visible mapped Vulkan buffers, terrain_upload.rs:65-82), its device twin, a stream for the transfer and two events
 int slab_resources(RtContext* ctx) {
     const size_t n = (size_t)RT_SLICE_SIZE * (size_t)ctx->region * (size_t)ctx->region;
-    if (!ctx->d_slab_mat) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mat, n));
-    if (!ctx->d_slab_mine) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mine, n));
-    if (!ctx->h_slab_mat) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_mat, n * sizeof(uint32_t), hipHostMallocDefault));
-    if (!ctx->h_slab_mine) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_mine, n, hipHostMallocDefault));
+    for (int k = 0; k < 2; k++) {
+        if (!ctx->d_slab_mat[k]) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mat[k], n));
+        if (!ctx->d_slab_mine[k]) RT_HIP(ctx, dev_alloc(ctx, &ctx->d_slab_mine[k], n));
+        if (!ctx->h_slab_mat[k]) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_mat[k], n * sizeof(uint32_t), hipHostMallocDefault));
+        if (!ctx->h_slab_mine[k]) RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_slab_mine[k], n, hipHostMallocDefault));
+        if (!ctx->ev_slab_copied[k]) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_copied[k], hipEventDisableTiming));
+        if (!ctx->ev_slab_applied[k]) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_applied[k], hipEventDisableTiming));
+    }
     if (!ctx->upload_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
-    if (!ctx->ev_slab_copied) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_copied, hipEventDisableTiming));
-    if (!ctx->ev_slab_applied) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_applied, hipEventDisableTiming));
     return RT_OK;
 }
 }  // namespace
@@ -668,8 +672,9 @@ int rt_slice_staging(RtContext* ctx, uint32_t** materials, uint8_t** minefield) 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     int rc = slab_resources(ctx);
     if (rc != RT_OK) return rc;
-    if (ctx->slab_copy_pending) { RT_HIP(ctx, hipEventSynchronize(ctx->ev_slab_copied)); ctx->slab_copy_pending = false; }   // the previous slab has left it
-    *materials = ctx->h_slab_mat; *minefield = ctx->h_slab_mine;
+    const int k = (int)(ctx->slabs & 1u);   // the set the NEXT rt_upload_slice uses
+    if (ctx->slab_copy_pending[k]) { RT_HIP(ctx, hipEventSynchronize(ctx->ev_slab_copied[k])); ctx->slab_copy_pending[k] = false; }   // the slab before last has left it
+    *materials = ctx->h_slab_mat[k]; *minefield = ctx->h_slab_mine[k];
     return RT_OK;
 }
 
@@ -689,7 +694,8 @@ int rt_upload_slice(RtContext* ctx, int axis, int texel_offset, const uint32_t* 
     // until then by stream order — the host waits for nothing on the device (the reference blocks on vkQueueWaitIdle here,
     // pipeline.rs:181-189); only a previous slab still leaving the pinned staging is waited for.
     const size_t n = (size_t)RT_SLICE_SIZE * kR * kR;
-    if (ctx->slab_copy_pending) { RT_HIP(ctx, hipEventSynchronize(ctx->ev_slab_copied)); ctx->slab_copy_pending = false; }
+    const int k = (int)(ctx->slabs & 1u);
+    if (ctx->slab_copy_pending[k]) { RT_HIP(ctx, hipEventSynchronize(ctx->ev_slab_copied[k])); ctx->slab_copy_pending[k] = false; }
     if ((ctx->cfg.flags & RT_FLAG_TRUSTED_WORLD) == 0) {
         // values above 30 are rejected as in rt_upload_world — BEFORE anything is written or transferred: a rejected slab leaves
         // the region (and what can be drawn) as it was.  The bytes are in host memory, so the check is a host loop over 16 R^2
@@ -699,22 +705,23 @@ int rt_upload_slice(RtContext* ctx, int axis, int texel_offset, const uint32_t* 
         if (worst > rtd::kMaxStepValue)
             return fail(ctx, RT_ERR_INVALID_ARG, "minefield slab holds a value above 30 (the reference writes 0..6, src/world/chunk.rs:163-183); the region is unchanged");
     }
-    if (materials != ctx->h_slab_mat) memcpy(ctx->h_slab_mat, materials, n * sizeof(uint32_t));   // borrowed buffers are released at return;
-    if (minefield != ctx->h_slab_mine) memcpy(ctx->h_slab_mine, minefield, n);                     // rt_slice_staging's pointers need no copy
-    if (ctx->slab_apply_recorded) RT_HIP(ctx, hipStreamWaitEvent(ctx->upload_stream, ctx->ev_slab_applied, 0));   // the previous slab's re-tile has read the device staging
-    RT_HIP(ctx, hipMemcpyAsync(ctx->d_slab_mine, ctx->h_slab_mine, n, hipMemcpyHostToDevice, ctx->upload_stream));
-    RT_HIP(ctx, hipMemcpyAsync(ctx->d_slab_mat, ctx->h_slab_mat, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->upload_stream));
-    RT_HIP(ctx, hipEventRecord(ctx->ev_slab_copied, ctx->upload_stream));
-    ctx->slab_copy_pending = true;
-    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slab_copied, 0));
+    if (materials != ctx->h_slab_mat[k]) memcpy(ctx->h_slab_mat[k], materials, n * sizeof(uint32_t));   // borrowed buffers are released at return;
+    if (minefield != ctx->h_slab_mine[k]) memcpy(ctx->h_slab_mine[k], minefield, n);                     // rt_slice_staging's pointers need no copy
+    if (ctx->slab_apply_recorded[k]) RT_HIP(ctx, hipStreamWaitEvent(ctx->upload_stream, ctx->ev_slab_applied[k], 0));   // the re-tile of the slab before last has read this device staging
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_slab_mine[k], ctx->h_slab_mine[k], n, hipMemcpyHostToDevice, ctx->upload_stream));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_slab_mat[k], ctx->h_slab_mat[k], n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->upload_stream));
+    RT_HIP(ctx, hipEventRecord(ctx->ev_slab_copied[k], ctx->upload_stream));
+    ctx->slab_copy_pending[k] = true;
+    ctx->slabs++;
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slab_copied[k], 0));
     RT_HIP(ctx, join_lanes_into(ctx, ctx->stream));   // frames in flight on the other lane read the region too
     {
         LaunchTimer t(ctx, 1);
-        RT_HIP(ctx, rtd::launch_flatten_slab(ctx->d_slab_mine, ctx->d_slab_mat, ctx->d_mine_sw, ctx->d_mat_sw, ctx->d_coarse,
-                                             ctx->logr, axis, texel_offset, ctx->stream));
+        RT_HIP(ctx, rtd::launch_flatten_slab(ctx->d_slab_mine[k], ctx->d_slab_mat[k], ctx->d_mine_sw, ctx->d_mat_sw, ctx->d_coarse,
+                                             ctx->d_brick, ctx->logr, axis, texel_offset, ctx->stream));
     }
-    RT_HIP(ctx, hipEventRecord(ctx->ev_slab_applied, ctx->stream));
-    ctx->slab_apply_recorded = true;
+    RT_HIP(ctx, hipEventRecord(ctx->ev_slab_applied[k], ctx->stream));
+    ctx->slab_apply_recorded[k] = true;
     RT_HIP(ctx, fence_lanes_after(ctx, ctx->stream));   // ... and later frames, whichever lane they start on, see the slab
     return RT_OK;
 }

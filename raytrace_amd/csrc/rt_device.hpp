@@ -38,7 +38,11 @@ __device__ __forceinline__ uint32_t coarse_index(int ix, int iy, int iz, int log
 struct Scene {
     const uint8_t* mine;      // u8[256^3]  brick-swizzled minefield (raytrace.comp binding 1)
     const uint32_t* mat;      // u32[256^3] brick-swizzled packed materials (binding 0)
-    const uint32_t* coarse;   // u32[32768] nibble per brick: common value 0..14, or 15 = mixed
+    const uint32_t* coarse;   // u32[32768] nibble per coarse cube (edge R/64; the 4^3 brick at R = 256): common value 0..14, or 15 = mixed
+    const uint8_t* brick;     // R > 256 (round 4): the same nibble per 4^3 BRICK, (R/4)^3 of them (1 MiB at 512, 8 MiB at 1024), in global
+                              // memory — consulted when the cube's entry says "mixed", so that only bricks whose 64 voxels really
+                              // differ cost a byte from the 1 GiB array (one 64-byte line each).  Entry of swizzled voxel index v:
+                              // nibble (v >> 6) & 1 of byte v >> 7.  At R = 256 it IS the coarse map (same pointer, never consulted).
     const uint32_t* noise;    // u32[512*512] RGBA8 blue noise (binding 9), R in the low byte
 };
 

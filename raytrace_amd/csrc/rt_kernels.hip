@@ -103,6 +103,28 @@ __global__ __launch_bounds__(256) void k_build_coarse(const uint8_t* __restrict_
     coarse[w] = word;
 }
 
+// Regions above 256 (round 4): the per-BRICK nibble map behind the coarse one (Scene::brick).  One thread per word = 8 x-adjacent
+// bricks; brick (bz, by, bx) is 64 consecutive bytes of the swizzled minefield at index ((bz << lb | by) << lb | bx) << 6.
+// (word0, nwords): the box of words to rebuild, in (x word, brick y, brick z) — everything for an upload, a slab's for rt_upload_slice.
+__global__ __launch_bounds__(256) void k_build_brick(const uint8_t* __restrict__ mine_sw, uint32_t* __restrict__ brick_words, int lb,
+                                                     uint3 word0, uint3 nwords) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= nwords.x * nwords.y * nwords.z) return;
+    const uint32_t wx = word0.x + t % nwords.x, by = word0.y + (t / nwords.x) % nwords.y, bz = word0.z + t / (nwords.x * nwords.y);
+    const uint32_t w = (((bz << lb) + by) << (lb - 3)) + wx;      // word index: 8 bricks per word along x
+    uint32_t word = 0;
+    for (uint32_t b = 0; b < 8u; b++) {
+        const uint4* src = reinterpret_cast<const uint4*>(mine_sw + ((size_t)(w * 8u + b) << 6));
+        const uint4 a = src[0], q = src[1], d = src[2], e = src[3];
+        const uint32_t first = a.x & 0xFFu, splat = first * 0x01010101u;
+        const uint32_t diff = (a.x ^ splat) | (a.y ^ splat) | (a.z ^ splat) | (a.w ^ splat) | (q.x ^ splat) | (q.y ^ splat) |
+                              (q.z ^ splat) | (q.w ^ splat) | (d.x ^ splat) | (d.y ^ splat) | (d.z ^ splat) | (d.w ^ splat) |
+                              (e.x ^ splat) | (e.y ^ splat) | (e.z ^ splat) | (e.w ^ splat);
+        word |= ((diff == 0u && first < kNibMixed) ? first : kNibMixed) << (4 * b);
+    }
+    brick_words[w] = word;
+}
+
 // =====================================================================================================
 // k_mega — one thread per pixel
 // =====================================================================================================
@@ -519,16 +541,21 @@ __global__ __launch_bounds__(256) void k_untile(const uint8_t* __restrict__ gath
 // Host-callable launchers (declared in rt_kernels.hpp)
 // =====================================================================================================
 hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
-                          uint32_t* coarse, uint32_t* bad_flag, int logr, hipStream_t st) {
+                          uint32_t* coarse, uint32_t* brick, uint32_t* bad_flag, int logr, hipStream_t st) {
     hipLaunchKernelGGL(k_flatten_voxels, dim3((1u << (3 * logr)) / 256u), dim3(256), 0, st, mine_lin, mat_lin, mine_sw, mat_sw,
                        bad_flag, logr);
     hipLaunchKernelGGL(k_build_coarse, dim3(kCoarseWords / 256), dim3(256), 0, st, mine_sw, coarse, logr, make_uint3(0, 0, 0),
                        make_uint3(8, 64, 64));
+    if (logr > 8 && brick != nullptr) {
+        const int lb = logr - 2;
+        const uint32_t nb = 1u << lb, n = (nb / 8u) * nb * nb;
+        hipLaunchKernelGGL(k_build_brick, dim3((n + 255u) / 256u), dim3(256), 0, st, mine_sw, brick, lb, make_uint3(0, 0, 0), make_uint3(nb / 8u, nb, nb));
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_flatten_slab(const uint8_t* mine_slab, const uint32_t* mat_slab, uint8_t* mine_sw, uint32_t* mat_sw, uint32_t* coarse,
-                               int logr, int axis, int offset, hipStream_t st) {
+                               uint32_t* brick, int logr, int axis, int offset, hipStream_t st) {
     const uint32_t R = 1u << logr;
     hipLaunchKernelGGL(k_flatten_slab, dim3(RT_SLICE_SIZE * R * R / 256u), dim3(256), 0, st, mine_slab, mat_slab, mine_sw, mat_sw,
                        logr, axis, offset);
@@ -542,6 +569,16 @@ hipError_t launch_flatten_slab(const uint8_t* mine_slab, const uint32_t* mat_sla
     else { w0.z = c0; nw.z = c1 - c0 + 1u; }
     const uint32_t n = nw.x * nw.y * nw.z;
     hipLaunchKernelGGL(k_build_coarse, dim3((n + 255u) / 256u), dim3(256), 0, st, mine_sw, coarse, logr, w0, nw);
+    if (logr > 8 && brick != nullptr) {   // the slab's four brick layers of the per-brick map (whole words along x)
+        const int lb = logr - 2;
+        const uint32_t nb = 1u << lb, b0 = (uint32_t)offset / 4u;
+        uint3 bw0 = make_uint3(0, 0, 0), bnw = make_uint3(nb / 8u, nb, nb);
+        if (axis == 0) { bw0.x = b0 / 8u; bnw.x = (b0 + 3u) / 8u - bw0.x + 1u; }
+        else if (axis == 1) { bw0.y = b0; bnw.y = 4u; }
+        else { bw0.z = b0; bnw.z = 4u; }
+        const uint32_t bn = bnw.x * bnw.y * bnw.z;
+        hipLaunchKernelGGL(k_build_brick, dim3((bn + 255u) / 256u), dim3(256), 0, st, mine_sw, brick, lb, bw0, bnw);
+    }
     return hipGetLastError();
 }
 

@@ -102,9 +102,9 @@ hipError_t launch_paths(const Scene& sc, const Frame& f, const Planes& pl, const
                         hipStream_t st);
 
 hipError_t launch_flatten(const uint8_t* mine_lin, const uint32_t* mat_lin, uint8_t* mine_sw, uint32_t* mat_sw,
-                          uint32_t* coarse, uint32_t* bad_flag, int logr, hipStream_t st);
+                          uint32_t* coarse, uint32_t* brick /* R > 256: the per-brick map, else null */, uint32_t* bad_flag, int logr, hipStream_t st);
 hipError_t launch_flatten_slab(const uint8_t* mine_slab, const uint32_t* mat_slab, uint8_t* mine_sw, uint32_t* mat_sw, uint32_t* coarse,
-                               int logr, int axis, int offset, hipStream_t st);
+                               uint32_t* brick, int logr, int axis, int offset, hipStream_t st);
 hipError_t launch_mega(const Scene& sc, const Frame& f, const Planes& pl, DevCounters* cn, bool count, hipStream_t st);
 hipError_t launch_trace(const Scene& sc, const Frame& f, const TraceArgs& a, bool primary, bool count, int nworkgroups, hipStream_t st);
 hipError_t launch_shade0(const Scene& sc, const Frame& f, const ShadeArgs& a, const Planes& pl, bool count, hipStream_t st);

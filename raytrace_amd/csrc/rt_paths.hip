@@ -67,6 +67,11 @@
 #ifndef RT_PATHS_SHADOW_REPS
 #define RT_PATHS_SHADOW_REPS 0x3
 #endif
+#ifndef RT_PATHS_BRICK_MAP
+#define RT_PATHS_BRICK_MAP 0    // regions above 256: 1 = consult a global per-brick nibble map (Scene::brick; RT_BRICK_MAP=1 makes the host build it) before
+                                // the byte array.  Measured and NOT kept: it answers 11 % of the loop's fetches at R = 1024 and costs every step on a
+                                // "mixed" cube one more dependent round trip: C5 128 -> 151 ms per frame (profiles/r4_c5_brick_map.txt)
+#endif
 
 namespace rtd {
 using namespace pslot;
@@ -113,6 +118,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
     const uint32_t stack_levels = D > 1u ? D - 1u : 1u;
     // minefield bytes as a buffer: a lane that needs no byte passes an out-of-range offset (no access, returns 0)
     const auto mine_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sc.mine), (short)0, 1 << (3 * LOGR), 0x00020000);
+    // regions above 256: the per-brick nibble map between the LDS map (one entry per (R/64)^3 cube) and the bytes — same trick, a
+    // lane whose cube is not "mixed" passes an offset beyond the map
+    const auto brick_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(sc.brick), (short)0, 1 << (3 * LOGR - 7), 0x00020000);
+    unsigned long long d_fetch = 0, d_fetch_cube = 0, d_fetch_brick = 0;   // counting builds: fetches of rays in flight / not answered by the LDS map / nor by the brick map
 
 #ifdef RT_DIAG_WAVE_TIMES
     const unsigned long long t_wave0 = wall_clock64();
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         uint32_t nb, nsh;
         ps_nibble_of<LOGR, LRZ>(vox, &nb, &nsh);
         uint32_t st = (s_nib[nb] >> nsh) & 15u;
+        if (LOGR > 8 && RT_PATHS_BRICK_MAP != 0 && st == kNibMixed) st = (sc.brick[vox >> 7] >> ((vox >> 4) & 4u)) & 15u;
         if (st == kNibMixed) st = sc.mine[vox];
         return st;
     };
@@ -479,20 +489,57 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         if (!LRZ) {   // the border texel reads as "mixed", and its byte offset is out of the buffer's range: value 0
             t1 |= (uint32_t)((int32_t)v1 >> 31) & 15u; t3 |= (uint32_t)((int32_t)v3_ >> 31) & 15u;
         }
-        const bool g1 = lm_lane(rFA & __ballot(t1 == kNibMixed)), g3 = lm_lane(rFB & __ballot(t3 == kNibMixed));   // only a ray in flight on a mixed cube fetches
+        const lanemask m1 = rFA & __ballot(t1 == kNibMixed), m3 = rFB & __ballot(t3 == kNibMixed);   // only a ray in flight on a mixed cube fetches
+        const bool g1 = lm_lane(m1), g3 = lm_lane(m3);
         uint32_t t0 = 0, t2 = 0, b0 = 0, b2 = 0;
         bool g0 = false, g2 = false;
+        lanemask m0 = 0, m2 = 0;
         if (SHADOW) {
             t0 = __builtin_amdgcn_ubfe(w0, h0, 4u); t2 = __builtin_amdgcn_ubfe(w2, h2, 4u);
             if (!LRZ) { t0 |= (uint32_t)((int32_t)v0 >> 31) & 15u; t2 |= (uint32_t)((int32_t)v2 >> 31) & 15u; }
-            g0 = lm_lane(rSA & __ballot(t0 == kNibMixed)); g2 = lm_lane(rSB & __ballot(t2 == kNibMixed));
-            b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
+            m0 = rSA & __ballot(t0 == kNibMixed); m2 = rSB & __ballot(t2 == kNibMixed);
+            g0 = lm_lane(m0); g2 = lm_lane(m2);
         }
-        const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g1 ? v1 : 0xFFFFFFFFu, 0, 0);
-        if (SHADOW) b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
-        const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g3 ? v3_ : 0xFFFFFFFFu, 0, 0);
-        t1 = g1 ? b1 : t1; t3 = g3 ? b3 : t3;
-        if (SHADOW) { t0 = g0 ? b0 : t0; t2 = g2 ? b2 : t2; }
+        if (COUNT) {
+            d_fetch += (uint32_t)__popcll(rFA) + (uint32_t)__popcll(rFB) + (SHADOW ? (uint32_t)__popcll(rSA) + (uint32_t)__popcll(rSB) : 0u);
+            d_fetch_cube += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m3) + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m2);
+        }
+        if constexpr (LOGR > 8 && RT_PATHS_BRICK_MAP != 0) {
+            // second level (round 4): the brick's own nibble from the global per-brick map (L2-resident: 1 MiB / 8 MiB); the byte
+            // array is read only by lanes whose BRICK is mixed.  At R = 1024 a cube of the LDS map is 16^3 voxels and most cubes
+            // near the terrain read "mixed" although 60-80 % of their 4^3 bricks are uniform: this turns those fetches from one
+            // 64-byte line of a 1 GiB array each into hits in an 8 MiB map.
+            uint32_t u0 = 0, u2 = 0;
+            if (SHADOW) u0 = __builtin_amdgcn_raw_buffer_load_b8(brick_rsrc, g0 ? v0 >> 7 : 0xFFFFFFFFu, 0, 0);
+            uint32_t u1 = __builtin_amdgcn_raw_buffer_load_b8(brick_rsrc, g1 ? v1 >> 7 : 0xFFFFFFFFu, 0, 0);
+            if (SHADOW) u2 = __builtin_amdgcn_raw_buffer_load_b8(brick_rsrc, g2 ? v2 >> 7 : 0xFFFFFFFFu, 0, 0);
+            uint32_t u3 = __builtin_amdgcn_raw_buffer_load_b8(brick_rsrc, g3 ? v3_ >> 7 : 0xFFFFFFFFu, 0, 0);
+            u1 = __builtin_amdgcn_ubfe(u1, (v1 >> 4) & 4u, 4u); u3 = __builtin_amdgcn_ubfe(u3, (v3_ >> 4) & 4u, 4u);
+            const lanemask n1 = m1 & __ballot(u1 == kNibMixed), n3 = m3 & __ballot(u3 == kNibMixed);
+            const bool k1 = lm_lane(n1), k3 = lm_lane(n3);
+            bool k0 = false, k2 = false;
+            lanemask n0 = 0, n2 = 0;
+            if (SHADOW) {
+                u0 = __builtin_amdgcn_ubfe(u0, (v0 >> 4) & 4u, 4u); u2 = __builtin_amdgcn_ubfe(u2, (v2 >> 4) & 4u, 4u);
+                n0 = m0 & __ballot(u0 == kNibMixed); n2 = m2 & __ballot(u2 == kNibMixed);
+                k0 = lm_lane(n0); k2 = lm_lane(n2);
+                b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, k0 ? v0 : 0xFFFFFFFFu, 0, 0);
+            }
+            if (COUNT) d_fetch_brick += (uint32_t)__popcll(n1) + (uint32_t)__popcll(n3) + (uint32_t)__popcll(n0) + (uint32_t)__popcll(n2);
+            const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, k1 ? v1 : 0xFFFFFFFFu, 0, 0);
+            if (SHADOW) b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, k2 ? v2 : 0xFFFFFFFFu, 0, 0);
+            const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, k3 ? v3_ : 0xFFFFFFFFu, 0, 0);
+            t1 = g1 ? (k1 ? b1 : u1) : t1; t3 = g3 ? (k3 ? b3 : u3) : t3;
+            if (SHADOW) { t0 = g0 ? (k0 ? b0 : u0) : t0; t2 = g2 ? (k2 ? b2 : u2) : t2; }
+        } else {
+            if (COUNT) d_fetch_brick += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m3) + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m2);
+            if (SHADOW) b0 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g0 ? v0 : 0xFFFFFFFFu, 0, 0);
+            const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g1 ? v1 : 0xFFFFFFFFu, 0, 0);
+            if (SHADOW) b2 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g2 ? v2 : 0xFFFFFFFFu, 0, 0);
+            const uint32_t b3 = __builtin_amdgcn_raw_buffer_load_b8(mine_rsrc, g3 ? v3_ : 0xFFFFFFFFu, 0, 0);
+            t1 = g1 ? b1 : t1; t3 = g3 ? b3 : t3;
+            if (SHADOW) { t0 = g0 ? b0 : t0; t2 = g2 ? b2 : t2; }
+        }
         if (SHADOW) p_step<false, LOGR, LRZ, CAREFUL>(SA, rSA, nul, nul2, t0, swz, f.lr[0], f.lr[1], f.lr[2]);
         p_step<true, LOGR, LRZ, CAREFUL>(FA, rFA, zFA, xyFA, t1, swz, f.lr[0], f.lr[1], f.lr[2]);
         if (SHADOW) p_step<false, LOGR, LRZ, CAREFUL>(SB, rSB, nul, nul2, t2, swz, f.lr[0], f.lr[1], f.lr[2]);
@@ -552,8 +599,10 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
 #ifndef RT_DIAG_WAVE_TIMES
             atomicAdd(&cn->dbg_loop_iters, d_iters); atomicAdd(&cn->dbg_f_lanes, d_live);
             atomicAdd(&cn->dbg_passes, d_passf); atomicAdd(&cn->dbg_pass_lanes, d_plf);
+            // where the step loop's fetches are answered (tools/fetch_levels.py): all / beyond the LDS map / beyond the brick map
+            atomicAdd(&cn->dbg_s_execs, d_fetch); atomicAdd(&cn->dbg_s_lanes, d_fetch_cube); atomicAdd(&cn->dbg_sky_lanes, d_fetch_brick);
 #else       // wave lifetimes on the 100 MHz clock (tools/drain_times.py reads them from RT_DEBUG_STATS' raw lines)
-            (void)d_iters; (void)d_live; (void)d_passf; (void)d_plf;
+            (void)d_iters; (void)d_live; (void)d_passf; (void)d_plf; (void)d_fetch; (void)d_fetch_cube; (void)d_fetch_brick;
             const unsigned long long t1 = wall_clock64();
             atomicAdd(&cn->dbg_s_execs, t1 - t_wave0); atomicMax(&cn->dbg_f_execs, t1); atomicMax(&cn->dbg_sky_lanes, ~t_wave0);
             atomicAdd(&cn->dbg_s_lanes, t_exh ? t1 - t_exh : 0ull);

@@ -57,6 +57,7 @@ class Context:
 
     # -- lifecycle ---------------------------------------------------------------------------------------
     def destroy(self):
+        self._retire_staging_views()
         if self._h and self._owned:
             self._lib.rt_destroy(self._h)
         self._h = None
@@ -92,13 +93,21 @@ class Context:
 
     def slice_staging(self):
         """rt_slice_staging: (materials u32[16 R^2], minefield u8[16 R^2]) views of the library's pinned slab staging — fill them
-        and pass them to upload_slice to skip the copy into the staging buffer."""
+        and pass them to upload_slice to skip the copy into the staging buffer.  The memory belongs to the context: the views are
+        writable from this call until the next upload_slice (which hands the buffer to the device and makes them read-only: there
+        are two staging sets, ask again for every slab) and dead after destroy() — do not keep them."""
         pm, pf = C.c_void_p(), C.c_void_p()
         self._check(self._lib.rt_slice_staging(self._h, C.byref(pm), C.byref(pf)))
         n = 16 * (self.cfg.region if self.cfg is not None else 256) ** 2
         mats = np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint32)), shape=(n,))
         mine = np.ctypeslib.as_array(C.cast(pf, C.POINTER(C.c_uint8)), shape=(n,))
+        self._staging_views = (mats, mine)
         return mats, mine
+
+    def _retire_staging_views(self):
+        for v in getattr(self, "_staging_views", None) or ():
+            v.flags.writeable = False       # a write after the hand-over would race with the host-to-device copy
+        self._staging_views = None
 
     def upload_slice(self, axis, texel_offset, materials, minefield):
         materials = np.ascontiguousarray(materials, dtype=np.uint32).reshape(-1)
@@ -106,7 +115,10 @@ class Context:
         n = 16 * (self.cfg.region if self.cfg is not None else 256) ** 2
         if materials.size != n or minefield.size != n:
             raise ValueError("slice arrays must hold 16*region*region voxels")
-        self._check(self._lib.rt_upload_slice(self._h, int(axis), int(texel_offset), _p(materials), _p(minefield)))
+        try:
+            self._check(self._lib.rt_upload_slice(self._h, int(axis), int(texel_offset), _p(materials), _p(minefield)))
+        finally:
+            self._retire_staging_views()
 
     def upload_noise(self, rgba8):
         rgba8 = np.ascontiguousarray(rgba8, dtype=np.uint8).reshape(-1)

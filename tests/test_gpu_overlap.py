@@ -207,7 +207,7 @@ def test_default_kernel_switches_to_k_paths_for_one_sample_frames_of_three_milli
     for y0 in (400, 1000):
         band, _ = po.render(mats, mine, blue_noise, u, W, H, 1, depth, rows=(y0, y0 + 8))
         for name in band:
-            assert np.array_equal(got[name][y0:y0 + 8], band[name], equal_nan=True), (name, y0)
+            assert np.array_equal(got[name][y0:y0 + 8], band[name][y0:y0 + 8], equal_nan=True), (name, y0)
     with render.Context(render.make_config(1024, 1024, spp=1, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY)) as ctx:
         ctx.upload_world(mats, mine)
         ctx.upload_noise(blue_noise)

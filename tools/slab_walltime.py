@@ -1,7 +1,9 @@
 """rt_upload_slice as the host sees it: wall time of the CALL (time.perf_counter around the ctypes call, arrays
 prepared beforehand), R = 256 and 512, validated / RT_FLAG_TRUSTED_WORLD, caller-owned buffers / the library's pinned staging
 (rt_slice_staging), with the stream idle and with a frame in flight (1920x1080 spp 16: the call must not wait for it).
-Prints one JSON line per case -> profiles/r3_slab_walltime.jsonl."""
+Round 4: also THREE slabs back to back behind a frame in flight — with two staging sets the first two calls return at
+once and the third waits for the first slab's re-tile, i.e. for the frame in front of it (one slab per frame never waits).
+Prints one JSON line per case -> profiles/r4_slab_walltime.jsonl."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -52,3 +54,16 @@ for region in (256, 512):
                                       "frame_in_flight": busy, "frame_ms": round(frame_ms, 3) if busy else None, "calls": len(times),
                                       "call_ms_median": round(times[len(times) // 2], 4), "call_ms_min": round(times[0], 4), "call_ms_max": round(times[-1], 4),
                                       "fill_ms_median": round(sorted(fill)[len(fill) // 2], 4) if fill else None}), flush=True)
+            # three slabs back to back behind a frame in flight: per position in the burst
+            burst = [[], [], []]
+            for rep in range(6):
+                ctx.sync()
+                ctx.draw_frame(u)
+                for k in range(3):
+                    axis, off, sm, sf = slabs[(3 * rep + k) % len(slabs)]
+                    t0 = time.perf_counter()
+                    ctx.upload_slice(axis, off, sm, sf)
+                    burst[k].append((time.perf_counter() - t0) * 1e3)
+            ctx.sync()
+            print(json.dumps({"region": region, "validated": not trusted, "case": "three slabs back to back behind a frame in flight (caller-owned buffers)",
+                              "frame_ms": round(frame_ms, 3), "call_ms_median_by_position": [round(sorted(b)[len(b) // 2], 4) for b in burst]}), flush=True)
