@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-COUNTERS_FILE = "r3_counters.json"   # written by tools/pmc_to_json.py on the GPU box (tools/profile_r3.sh)
+COUNTERS_FILE = "r4_counters.json"   # written by tools/pmc_to_json.py on the GPU box (tools/profile_r4.sh)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 KERNEL_NAMES = {"paths": "k_paths", "persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}
 
@@ -310,6 +310,8 @@ def main():
         # latency of ONE frame — draw, (gather,) wait, nothing else in flight: the reference's per-frame fence (pipeline.rs:162-172).
         # Before the timed region (so that the last timed frame stays the frame that is hashed), with the first frame's seed.
         lat = []
+        if warmup > 0:
+            ctx.timing()
         for _ in range(3 if warmup > 0 else 0):
             t1 = time.perf_counter()
             step(fixed=True)
@@ -317,7 +319,11 @@ def main():
             lat.append(time.perf_counter() - t1)
             fence()
         rec["latency_ms"] = sorted(lat)[len(lat) // 2] * 1e3 if lat else None
-        ctx.timing()          # drop the warm-up frames' launch events
+        # the path kernel's launches with nothing else in flight (their events during the latency frames): with two launches in
+        # flight a launch's own begin-to-end time also holds the time it waits for the CUs of the launch in front of it
+        rec["alone_trace_ms"], rec["alone_trace_launches"] = (lambda t: (t.trace_ms, t.trace_launches))(ctx.timing()) if lat else (0.0, 0)
+        if warmup > 0:
+            ctx.timing()      # drop the warm-up frames' launch events
         ctx.gather_timing()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -371,7 +377,14 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "launches_per_frame": launches_per_frame, "avg_launch_ms": round(avg_launch_ms, 4),
                     "algorithmic_bytes_per_launch": int(r["trace_bytes"] / max(launches_per_frame, 1)),
-                    "samples_per_launch": int(r["samples_per_launch"])}
+                    "samples_per_launch": int(r["samples_per_launch"]), "launches_in_flight": int(r["launches_in_flight"])}
+        if r.get("alone_trace_launches"):
+            # `achieved` / `frac` follow the contract (launch duration over the timed region: with two launches in flight a launch's
+            # begin-to-end time includes its slow start on the CUs the launch in front of it is still leaving); the same kernel with
+            # nothing else in flight, from the one-frame latency runs:
+            alone_ms = r["alone_trace_ms"] / r["alone_trace_launches"]
+            ach1 = r["trace_bytes"] / max(launches_per_frame, 1) / (alone_ms * 1e-3) / 1e9
+            roofline["one_launch_in_flight"] = {"avg_launch_ms": round(alone_ms, 4), "achieved": round(ach1, 2), "frac": round(ach1 / HBM_PEAK_GBS, 5)}
         if world > 1:
             roofline["rank"] = 0
             roofline["ranks_path_kernel_ms_per_frame"] = {"min": round(r["rank_trace_ms"][0] / max(steps, 1), 4), "max": round(r["rank_trace_ms"][1] / max(steps, 1), 4)}
@@ -388,6 +401,9 @@ def main():
                                             "bytes_per_launch": prof["hbm_bytes_per_launch"], "l2_hit_rate": prof.get("l2_hit_rate")}
             if "valu" in prof:
                 roofline["valu"] = prof["valu"]
+            # the launch sizing depends on the memory free at rt_create; say so if this run's differs from the profiled one
+            if prof.get("samples_per_launch") not in (None, int(r["samples_per_launch"])):
+                roofline["profile_samples_per_launch_differs"] = {"profile": prof.get("samples_per_launch"), "run": int(r["samples_per_launch"])}
         return roofline
 
     def reference_frame():

@@ -473,8 +473,16 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
 
     // ---- one step of all four rays: nibble reads, then byte loads, then the arithmetic ----
     // SHADOW: the shadow rays step too.  CAREFUL: the steps test the iteration counter (p_step).
+#ifdef RT_DIAG_STEP_TIMES   // where a step's time goes once the paths have run out (shader-clock ticks; tools/lab/r4/step_times.py)
+    unsigned long long t_lds = 0, t_mem = 0, t_alu = 0, t_steps = 0, t_bytes = 0;
+#endif
     auto step_all = [&](auto shadow_tag, auto careful_tag) {
         constexpr bool SHADOW = decltype(shadow_tag)::value, CAREFUL = decltype(careful_tag)::value;
+#ifdef RT_DIAG_STEP_TIMES
+        const bool timed = exhausted;
+        unsigned long long tq0 = 0, tq1 = 0, tq2 = 0;
+        if (timed) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tq0 = clock64(); }
+#endif
         const uint32_t v1 = pr_vox(FA), v3_ = pr_vox(FB);
         uint32_t n1, n3, h1, h3;     // nibble-map byte and nibble offset of each ray's texel
         ps_nibble_of<LOGR, LRZ>(v1, &n1, &h1); ps_nibble_of<LOGR, LRZ>(v3_, &n3, &h3);
@@ -489,6 +497,9 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         if (!LRZ) {   // the border texel reads as "mixed", and its byte offset is out of the buffer's range: value 0
             t1 |= (uint32_t)((int32_t)v1 >> 31) & 15u; t3 |= (uint32_t)((int32_t)v3_ >> 31) & 15u;
         }
+#ifdef RT_DIAG_STEP_TIMES
+        if (timed) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq1 = clock64(); }
+#endif
         const lanemask m1 = rFA & __ballot(t1 == kNibMixed), m3 = rFB & __ballot(t3 == kNibMixed);   // only a ray in flight on a mixed cube fetches
         const bool g1 = lm_lane(m1), g3 = lm_lane(m3);
         uint32_t t0 = 0, t2 = 0, b0 = 0, b2 = 0;
@@ -540,10 +551,23 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             t1 = g1 ? b1 : t1; t3 = g3 ? b3 : t3;
             if (SHADOW) { t0 = g0 ? b0 : t0; t2 = g2 ? b2 : t2; }
         }
+#ifdef RT_DIAG_STEP_TIMES
+        if (timed) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tq2 = clock64();
+            t_bytes += (uint32_t)__popcll(__ballot(g1)) + (uint32_t)__popcll(__ballot(g3)) + (uint32_t)__popcll(__ballot(g0)) + (uint32_t)__popcll(__ballot(g2));
+        }
+#endif
         if (SHADOW) p_step<false, LOGR, LRZ, CAREFUL>(SA, rSA, nul, nul2, t0, swz, f.lr[0], f.lr[1], f.lr[2]);
         p_step<true, LOGR, LRZ, CAREFUL>(FA, rFA, zFA, xyFA, t1, swz, f.lr[0], f.lr[1], f.lr[2]);
         if (SHADOW) p_step<false, LOGR, LRZ, CAREFUL>(SB, rSB, nul, nul2, t2, swz, f.lr[0], f.lr[1], f.lr[2]);
         p_step<true, LOGR, LRZ, CAREFUL>(FB, rFB, zFB, xyFB, t3, swz, f.lr[0], f.lr[1], f.lr[2]);
+#ifdef RT_DIAG_STEP_TIMES
+        if (timed) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tq3 = clock64();
+            t_lds += tq1 - tq0; t_mem += tq2 - tq1; t_alu += tq3 - tq2; t_steps++;
+        }
+#endif
     };
     // The loop limit (raytrace.comp:109).  The steps of the main loop only count a ray's iterations; every 16th look the wave
     // asks whether a ray in flight has come within reach of the limit (16 looks = 48 iterations) and, if so, steps with the
@@ -600,7 +624,13 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
             atomicAdd(&cn->dbg_loop_iters, d_iters); atomicAdd(&cn->dbg_f_lanes, d_live);
             atomicAdd(&cn->dbg_passes, d_passf); atomicAdd(&cn->dbg_pass_lanes, d_plf);
             // where the step loop's fetches are answered (tools/fetch_levels.py): all / beyond the LDS map / beyond the brick map
+#ifdef RT_DIAG_STEP_TIMES
+            (void)d_fetch; (void)d_fetch_cube; (void)d_fetch_brick;
+            atomicAdd(&cn->dbg_s_execs, t_lds); atomicAdd(&cn->dbg_s_lanes, t_mem); atomicAdd(&cn->dbg_sky_lanes, t_alu);
+            atomicAdd(&cn->dbg_f_execs, t_steps); atomicAdd(&cn->dbg_loop_iters, t_bytes);
+#else
             atomicAdd(&cn->dbg_s_execs, d_fetch); atomicAdd(&cn->dbg_s_lanes, d_fetch_cube); atomicAdd(&cn->dbg_sky_lanes, d_fetch_brick);
+#endif
 #else       // wave lifetimes on the 100 MHz clock (tools/drain_times.py reads them from RT_DEBUG_STATS' raw lines)
             (void)d_iters; (void)d_live; (void)d_passf; (void)d_plf; (void)d_fetch; (void)d_fetch_cube; (void)d_fetch_brick;
             const unsigned long long t1 = wall_clock64();

@@ -2,7 +2,7 @@
 (hipcc -S), takes the shipped headline instantiation k_paths<false, 0, 8, true>, finds the step group (its largest basic block:
 RT_PATHS_STEPS_PER_CHECK repetitions of the four ray slots, ten slot-steps with the default 3 / 0x3), counts the opcodes and
 prices every VALU opcode with the issue cost measured by tools/ubench/valu_rate (profiles/r3_ubench_valu_rate.txt, the
-4-waves-per-SIMD column — the occupancy the kernel runs at).  Writes profiles/r3_step_loop_isa_hist.json; bench.py reads
+4-waves-per-SIMD column — the occupancy the kernel runs at).  Writes profiles/r4_step_loop_isa_hist.json; bench.py reads
 `cycles_per_valu_inst` from it for roofline.valu.pipe_busy_weighted.
 
     python tools/isa_hist.py            # run in the container (hipcc cross-compiles, no GPU needed)
@@ -95,7 +95,7 @@ def main():
         "unpriced_opcodes": unpriced, "valu_opcodes": table,
         "whole_kernel": {"valu_insts": sum(n for o, n in whole.items() if o.startswith("v_")), "basic_blocks": len(blocks)},
     }
-    path = os.path.join(ROOT, "profiles", "r3_step_loop_isa_hist.json")
+    path = os.path.join(ROOT, "profiles", "r4_step_loop_isa_hist.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "valu_opcodes"}, indent=1))
     print("%-24s %5s %7s" % ("opcode", "count", "cycles"))

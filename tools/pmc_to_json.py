@@ -1,11 +1,11 @@
-"""Condense the rocprofv3 passes of tools/profile_r3.sh into one JSON: per workload and kernel, per-launch averages of every
+"""Condense the rocprofv3 passes of tools/profile_r4.sh into one JSON: per workload and kernel, per-launch averages of every
 counter plus the derived figures bench.py attaches to its `roofline` record.  usage: pmc_to_json.py <prof dir>"""
 import csv, glob, hashlib, json, os, re, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = sys.argv[1]
 WORK = {"head": "1920x1080 spp=64 depth=4 region=256", "c5": "3840x2160 spp=1024 depth=8 region=1024",
-        "c4": "3840x2160 spp=256 depth=8 region=256"}
+        "c4": "3840x2160 spp=256 depth=8 region=256", "c5t": "3840x2160 spp=1024 depth=8 region=1024 pose=terrain"}
 SIMDS = 256 * 4
 
 
@@ -42,11 +42,11 @@ def stats(tagdir):
     return out
 
 
-res = {"kernel_source_sha16": source_sha16(), "tool": "tools/profile_r3.sh (rocprofv3, one --pmc set per pass)", "workloads": {}}
+res = {"kernel_source_sha16": source_sha16(), "tool": "tools/profile_r4.sh (rocprofv3, one --pmc set per pass)", "workloads": {}}
 # issue cost of the step loop's instruction mix (tools/isa_hist.py), if it was taken on these very sources
 CPI = None
 try:
-    _h = json.load(open(os.path.join(ROOT, "profiles", "r3_step_loop_isa_hist.json")))
+    _h = json.load(open(os.path.join(ROOT, "profiles", "r4_step_loop_isa_hist.json")))
     if _h.get("kernel_source_sha16") == res["kernel_source_sha16"]:
         CPI = float(_h["cycles_per_valu_inst"])
 except Exception:
@@ -68,7 +68,17 @@ for tag, wname in WORK.items():
             raw = per[k].setdefault("raw", {})
             for c, (v, n) in cs.items():
                 raw[c] = {"sum": v, "dispatches": n, "per_launch": v / n}
+    # the bench line of the kernel-trace pass: how the profiled context sized its launches (bench.py compares)
+    spl = None
+    try:
+        for l in open(os.path.join(prof, tag + "_stats.log")):
+            if l.startswith("{"):
+                spl = json.loads(l)["config"].get("samples_per_launch")
+    except Exception:
+        pass
     for k, r in per.items():
+        if spl is not None:
+            r["samples_per_launch"] = spl
         raw = r.get("raw", {})
         g = lambda c: raw[c]["per_launch"] if c in raw else None
         if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
@@ -88,7 +98,7 @@ for tag, wname in WORK.items():
                 # wave64 instruction for fma/mul/add/and/or/lshr/mov, 3.4 for select/compare/convert/floor/bfi/min3/packed
                 "pipe_busy_if_all_2cyc": round(g("SQ_INSTS_VALU") * 2.0 / (SIMDS * cycles), 3),
                 "pipe_busy_if_all_3.4cyc": round(g("SQ_INSTS_VALU") * 3.4 / (SIMDS * cycles), 3),
-                # ... and at the measured cost of the step loop's own instruction mix (profiles/r3_step_loop_isa_hist.json:
+                # ... and at the measured cost of the step loop's own instruction mix (profiles/r4_step_loop_isa_hist.json:
                 # per-opcode counts of the step group x the micro-benchmark's issue cost), k_paths only
                 "pipe_busy_weighted": round(g("SQ_INSTS_VALU") * CPI / (SIMDS * cycles), 3) if (CPI and k == "k_paths") else None,
                 "cycles_per_valu_inst": CPI if k == "k_paths" else None,

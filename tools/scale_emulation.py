@@ -5,7 +5,7 @@ clock over a few frames enqueued back to back (the path kernel's share from its 
 slowest and fastest rank, and N=1 time / slowest rank = the speed-up the RENDERING allows (load balance + fixed per-launch costs); the RCCL gather (23 B per pixel to rank 0 over xGMI) is not in it.
 An emulation, not a scaling measurement: each rank has the whole GPU's caches and memory system to itself, as on its own GPU.
 
-    python tools/scale_emulation.py [headline|c4]     -> one JSON line per workload (profiles/r3_scale_emulation.jsonl)
+    python tools/scale_emulation.py [headline|c4]     -> one JSON line per workload (profiles/r4_scale_emulation.jsonl; SCALE_FIF=1|2 frames in flight)
 """
 import json, os, sys, time
 import numpy as np
@@ -18,15 +18,16 @@ mats, mine = world.generate_region(world.DEFAULT_SEED)
 u = render.camera_uniforms(render.DEFAULT_POSE["origin"], render.DEFAULT_POSE["heading"], render.DEFAULT_POSE["pitch"],
                            render.DEFAULT_POSE["sun_angle"], seed=1)
 NS = [int(x) for x in os.environ.get("SCALE_N", "1,2,4,8").split(",")]
+FIF = int(os.environ.get("SCALE_FIF", "2"))      # frames in flight, as bench.py's default (RT_FLAG_FRAMES_IN_FLIGHT_2); 1 = round 3's discipline
 for name in (sys.argv[1:] or ["headline", "c4"]):
     W, H, spp, depth, frames = WORK[name]
     out = {"workload": "%dx%d spp=%d depth=%d" % (W, H, spp, depth), "method": "ranks rendered one after the other on one MI355X (tools/scale_emulation.py); gather not included",
-           "frames_per_rank": frames, "n": {}}
+           "frames_per_rank": frames, "frames_in_flight": FIF, "n": {}}
     base = None
     for N in NS:
         per_rank, per_rank_pk = [], []
         for r in range(N):
-            cfg = render.make_config(W, H, spp=spp, depth=depth, tile_rank=r, tile_world=N, flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_TIMING)
+            cfg = render.make_config(W, H, spp=spp, depth=depth, tile_rank=r, tile_world=N, flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_TIMING | (abi.RT_FLAG_FRAMES_IN_FLIGHT_2 if FIF == 2 else 0))
             with render.Context(cfg) as ctx:
                 ctx.upload_world(mats, mine)
                 ctx.upload_noise(noise)
