@@ -102,6 +102,11 @@ typedef enum RtKernel {
                                  the step loop is branch-free; frames it does not cover (no primary cache)
                                  run on RT_KERNEL_PERSISTENT                                                     */
     /* 6 was RT_KERNEL_SEQ (three paths per lane, one ray slot each): retired in round 4 (ABI 1.2), rejected by rt_create */
+    RT_KERNEL_FRAME = 7,      /* (ABI 1.3) the whole frame in ONE launch: a wave per 8x8 tile walks the tile's primary rays and then
+                                 every sample's path of each of its pixels (sums in registers; no prepass, worklist, light records or
+                                 accumulate launch).  What RT_KERNEL_DEFAULT runs for frames with little work (the reference's own
+                                 1024 x 1024, 1 sample, depth 2).  Needs RT_FLAG_CACHE_PRIMARY and depth <= 8; other frames of such a
+                                 context run on RT_KERNEL_PATHS / RT_KERNEL_PERSISTENT                                          */
 } RtKernel;
 
 #define RT_FLAG_COUNTERS      0x1u  /* count rays/iterations/hits exactly (slower; for B_alg + parity)   */
@@ -376,9 +381,11 @@ int rt_get_gather_timing(RtContext* ctx, float* ms_sum, uint32_t* calls);
  *        no longer makes rt_draw_frame fail.
  *   1.2  round 4: RT_FLAG_FRAMES_IN_FLIGHT_2; RtInfo.launches_in_flight / frames_in_flight (in the former `reserved` word);
  *        rt_samples_per_launch, rt_get_gather_timing; RtKernel value 6 (SEQ) rejected by rt_create; the sample batches of a multi-launch frame run on two
- *        streams of the library (results unchanged; rt_set_stream(non-NULL) keeps everything on the caller's stream). */
+ *        streams of the library (results unchanged; rt_set_stream(non-NULL) keeps everything on the caller's stream).
+ *   1.3  round 4: RtKernel value 7 (RT_KERNEL_FRAME); RT_KERNEL_DEFAULT runs frames with little work on it (rt_kernel_in_use tells);
+ *        results unchanged. */
 #define RT_ABI_VERSION_MAJOR 1
-#define RT_ABI_VERSION_MINOR 2
+#define RT_ABI_VERSION_MINOR 3
 uint32_t rt_abi_version(void);
 
 #ifdef __cplusplus

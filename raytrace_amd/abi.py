@@ -20,7 +20,7 @@ RT_ERR_UNIMPLEMENTED = -5
 RT_ERR_OOM = -6
 
 RT_FLAG_TRUSTED_WORLD = 0x10
-RT_KERNEL_DEFAULT, RT_KERNEL_MEGA, RT_KERNEL_WAVEFRONT, RT_KERNEL_PERSISTENT, RT_KERNEL_PATHS = 0, 1, 2, 3, 5   # 4 (PERSISTENT2) and 6 (SEQ): retired
+RT_KERNEL_DEFAULT, RT_KERNEL_MEGA, RT_KERNEL_WAVEFRONT, RT_KERNEL_PERSISTENT, RT_KERNEL_PATHS, RT_KERNEL_FRAME = 0, 1, 2, 3, 5, 7   # 4 (PERSISTENT2) and 6 (SEQ): retired
 RT_FLAG_FRAMES_IN_FLIGHT_2 = 0x20
 RT_FLAG_COUNTERS = 0x1
 RT_FLAG_CACHE_PRIMARY = 0x2

@@ -26,7 +26,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contra
              "-Wall", "-Wno-unused-function"]
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra"]
 
-AMD_SRCS = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "rt_persist.hip"), os.path.join(CSRC, "rt_paths.hip"), os.path.join(CSRC, "rt_post.hip"),
+AMD_SRCS = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "rt_persist.hip"), os.path.join(CSRC, "rt_paths.hip"), os.path.join(CSRC, "rt_frame.hip"), os.path.join(CSRC, "rt_post.hip"),
             os.path.join(CSRC, "rt_api.hip")]
 AMD_DEPS = AMD_SRCS + [os.path.join(CSRC, "rt_device.hpp"), os.path.join(CSRC, "rt_kernels.hpp"), os.path.join(CSRC, "rt_dda.hpp"), os.path.join(CSRC, "rt_pslot.hpp"),
                        os.path.join(INC, "rt_abi.h"), os.path.join(INC, "rt_math.h")]

@@ -32,6 +32,11 @@ constexpr size_t kCursorWords = 8 * 32;   // path cursors of the persistent kern
 // RT_KERNEL_DEFAULT: launches of at least this many pixel-samples run on k_paths, smaller ones on k_persist (measured crossover,
 // round 3, same box: 1080p spp 1 (2.1 M) 0.351 against 0.348 ms per frame, spp 2 (4.1 M) 0.409 against 0.442; 1024^2 spp 1 0.252 against 0.229)
 constexpr uint64_t kPathsCrossover = 3ull << 20;
+// ... and ONE-sample frames of fewer pixels than this run on k_frame — the whole frame in one launch, no prepass, worklist or
+// accumulate (rt_frame.hip; RT_FRAME_CROSSOVER overrides).  Measured (profiles/r4_frame_kernel.txt), k_frame against prepass +
+// k_persist, ms per frame: 256^2 0.098 / 0.186, 1024^2 (the reference's frame) 0.176 / 0.225, 1920x1080 0.293 / 0.296; with more
+// than one sample per pixel a lane walks them one after the other and the persistent kernels win (256^2 spp 4: 0.200 / 0.188).
+constexpr uint64_t kFrameCrossover = 3ull << 19;
 // light records of one launch above which k_paths streams them out and k_accumulate_paths streams them in (see rt_draw_frame)
 constexpr uint64_t kStreamRecordBytes = 384ull << 20;
 
@@ -131,6 +136,10 @@ struct RtContext {
     uint32_t persist_threshold = 0, persist_rmin = 12;   // threshold 0 = the kernel version's default
     int persist_version = 1;      // 1 = k_persist, 3 = k_paths (RT_KERNEL_PATHS)
     bool paths_by_size = false;   // RT_KERNEL_DEFAULT: k_paths for launches with enough work, k_persist for small ones
+    int frame_mode = 0;           // k_frame: 0 = never, 1 = one-sample frames below frame_crossover pixels (RT_KERNEL_DEFAULT), 2 = every frame it covers (RT_KERNEL_FRAME)
+    uint64_t frame_crossover = kFrameCrossover;
+    uint32_t frame_threshold = 0; // RT_FRAME_THRESHOLD: parked lanes per wave that trigger k_frame's pass; 0 = the default
+    uint32_t frame_tiles = 0;     // RT_FRAME_TILES: tiles per wave of k_frame (1..4); 0 = by frame size
     int last_path_kernel = 0;     // RtKernel the most recent frame's path launches ran on (0 = no frame yet)
     float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
     bool lut_valid = false;
@@ -397,7 +406,8 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
     if (cfg->depth < 0 || cfg->depth > RT_MAX_DEPTH) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: depth out of range");
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: bad tile_rank/tile_world");
-    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_PATHS || cfg->kernel == 4 /* RT_KERNEL_PERSISTENT2, retired in round 3; 6 = RT_KERNEL_SEQ, round 4 */)
+    if (cfg->kernel < RT_KERNEL_DEFAULT || cfg->kernel > RT_KERNEL_FRAME || cfg->kernel == 4 /* RT_KERNEL_PERSISTENT2, retired in round 3 */ ||
+        cfg->kernel == 6 /* RT_KERNEL_SEQ, retired in round 4 */)
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown kernel");
 
     int ndev = 0;
@@ -422,7 +432,13 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         // RT_KERNEL_DEFAULT = k_paths (two paths, four ray slots per lane, branch-free step loop); the frames it does not
         // cover run on k_persist (rt_draw_frame decides per frame: lr is a per-frame uniform)
         c->paths_by_size = cfg->kernel == RT_KERNEL_DEFAULT;
-        c->kernel = cfg->kernel == RT_KERNEL_DEFAULT ? RT_KERNEL_PATHS : cfg->kernel;
+        // k_frame (one launch per frame) takes the small frames of RT_KERNEL_DEFAULT and whatever it covers of RT_KERNEL_FRAME; the
+        // rest of those contexts' frames go the persistent way, so they hold its buffers as well
+        c->frame_mode = cfg->kernel == RT_KERNEL_FRAME ? 2 : (cfg->kernel == RT_KERNEL_DEFAULT ? 1 : 0);
+        if (const char* s = getenv("RT_FRAME_CROSSOVER")) { long long v = atoll(s); if (v >= 0) c->frame_crossover = (uint64_t)v; }
+        if (const char* s = getenv("RT_FRAME_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->frame_threshold = (uint32_t)v; }
+        if (const char* s = getenv("RT_FRAME_TILES")) { int v = atoi(s); if (v >= 1 && v <= 4) c->frame_tiles = (uint32_t)v; }
+        c->kernel = (cfg->kernel == RT_KERNEL_DEFAULT || cfg->kernel == RT_KERNEL_FRAME) ? RT_KERNEL_PATHS : cfg->kernel;
         if (c->kernel == RT_KERNEL_PATHS) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 3; }
     }
     RT_HIP_CREATE(hipSetDevice(c->device));
@@ -458,7 +474,7 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
 
     // lanes and frame slots (see Lane / FrameSlot).  Two lanes for the persistent kernels; two slots when the host asks for two
     // frames in flight.  RT_LANES=1 / RT_FRAMES_IN_FLIGHT=1|2 override (experiments, A/B timing).
-    const bool persistent = cfg->kernel == RT_KERNEL_DEFAULT || cfg->kernel == RT_KERNEL_PERSISTENT || cfg->kernel == RT_KERNEL_PATHS;
+    const bool persistent = cfg->kernel == RT_KERNEL_DEFAULT || cfg->kernel == RT_KERNEL_PERSISTENT || cfg->kernel == RT_KERNEL_PATHS || cfg->kernel == RT_KERNEL_FRAME;
     c->nlanes = persistent ? 2 : 1;
     c->nslots = (persistent && (cfg->flags & RT_FLAG_FRAMES_IN_FLIGHT_2)) ? 2 : 1;
     if (const char* s = getenv("RT_LANES")) { int v = atoi(s); if (v == 1 || (v == 2 && persistent)) c->nlanes = v; }
@@ -772,7 +788,10 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         uint32_t* const wlc = fs.wl_count + 32 * fs.wl_parity;
         uint32_t* const wln = fs.wl_count + 32 * (fs.wl_parity ^ 1);
         const bool prepass_clears = cache && ctx->primary_version == 2 && ctx->npix_pad != 0;
-        if (e == hipSuccess && cache) {
+        // k_frame: the whole frame in one launch (cached primaries by construction; frames it does not cover go the persistent way)
+        const bool one_launch = cache && rtd::launch_frame_ok(f) &&
+                                (ctx->frame_mode == 2 || (ctx->frame_mode == 1 && ctx->cfg.spp == 1 && (uint64_t)ctx->npix_pad < ctx->frame_crossover));
+        if (e == hipSuccess && cache && !one_launch) {
             if (!fs.wl_clean[fs.wl_parity]) e = hipMemsetAsync(wlc, 0, sizeof(uint32_t), st0);
             fs.wl_clean[fs.wl_parity] = false;
             LaunchTimer t(ctx, 1, st0);
@@ -802,7 +821,16 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
             memcpy(ctx->lut_key, lut_key, sizeof(lut_key));
         }
         hipStream_t tail = st0;
-        if (e == hipSuccess && (!cache || ctx->cfg.depth >= 1)) {
+        if (e == hipSuccess && one_launch) {
+            ctx->path_launches++;   // (frames alternate between the lanes' streams like path launches do)
+            rtd::FrameArgs fa{};
+            fa.threshold = ctx->frame_threshold; fa.tiles_per_wave = ctx->frame_tiles; fa.sun_lut = ctx->sun_lut; fa.dif_lut = ctx->dif_lut; fa.counters = ctx->d_counters;
+            if (getenv("RT_DEBUG_WAVE_DUMP") && (size_t)ctx->ntiles_local * 32u <= (size_t)4 * ctx->num_cus * 1024 * sizeof(uint32_t))
+                fa.dbg_waves = reinterpret_cast<unsigned long long*>(ctx->lanes[0].pstack);   // (idle while k_frame runs)
+            LaunchTimer t(ctx, 0, st0);
+            ctx->last_path_kernel = RT_KERNEL_FRAME;
+            e = rtd::launch_frame(scene_of(ctx), f, fpl, fa, count, ctx->num_cus, st0);
+        } else if (e == hipSuccess && (!cache || ctx->cfg.depth >= 1)) {
             const uint32_t spp = (uint32_t)ctx->cfg.spp, B = ctx->persist_batch;
             if (nl == 2 && spp > B) e = hipEventRecord(fs.ev_prepass, st0);   // launches on the other lane wait for the prepass
             // one sample per pixel (the reference's own frames): k_persist and k_paths store the pixel's lighting themselves, no
@@ -1242,6 +1270,9 @@ int rt_get_info(RtContext* ctx, RtInfo* out) {
 int rt_kernel_in_use(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->last_path_kernel != 0) return ctx->last_path_kernel;   // what the last frame ran
+    if (ctx->kernel == RT_KERNEL_PERSISTENT && (ctx->cfg.flags & RT_FLAG_CACHE_PRIMARY) && ctx->cfg.depth <= 8 &&
+        (ctx->frame_mode == 2 || (ctx->frame_mode == 1 && ctx->cfg.spp == 1 && (uint64_t)ctx->npix_pad < ctx->frame_crossover)))
+        return RT_KERNEL_FRAME;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 3) return RT_KERNEL_PATHS;
     return ctx->kernel;
 }
@@ -1259,7 +1290,7 @@ int rt_get_counters(RtContext* ctx, RtCounters* out) {
     out->pixels = d.pixels; out->frames = ctx->host_frames;
     if (const char* path = getenv("RT_DEBUG_WAVE_DUMP")) {   // -DRT_DIAG_WAVE_TIMES builds of k_paths: per-wave (start, out of paths, end, workgroup)
         if (ctx->lanes[0].pstack) {
-            std::vector<unsigned long long> rec((size_t)ctx->num_cus * 16u * 4u);
+            std::vector<unsigned long long> rec(ctx->last_path_kernel == RT_KERNEL_FRAME ? ((size_t)ctx->ntiles_local + 3u) / 4u * 16u : (size_t)ctx->num_cus * 16u * 4u);
             if (hipMemcpy(rec.data(), ctx->lanes[0].pstack, rec.size() * sizeof(rec[0]), hipMemcpyDeviceToHost) == hipSuccess)
                 if (FILE* fp = fopen(path, "wb")) { fwrite(rec.data(), sizeof(rec[0]), rec.size(), fp); fclose(fp); }
         }

@@ -108,8 +108,9 @@ __device__ __forceinline__ void dda_advance(RaySlot2& r, uint32_t step, const Fr
 }
 
 // Head of trace_ray (:83-107) for a ray with direction d (already normalized, :83) from origin ro whose first texel is
-// (vox0, cidx0), ok = that texel is inside the texture.  r.l* (1/|d|, :88) must be set by the caller.
-template <int LOGR, bool LRZ, bool COUNT>
+// (vox0, cidx0), ok = that texel is inside the texture.  r.l* (1/|d|, :88) must be set by the caller.  DIRECT (k_frame): there
+// is no nibble map in LDS (s_nib unused), the value is the byte of the array.
+template <int LOGR, bool LRZ, bool COUNT, bool DIRECT = false>
 __device__ __forceinline__ void dda_arm(RaySlot2& r, float dx, float dy, float dz, float rox, float roy, float roz, bool ok,
                                         uint32_t vox0, uint32_t cidx0, const Frame& f, float half, const uint8_t* s_nib,
                                         const Scene& sc, unsigned long long& c_border, const uint32_t* s_swz) {
@@ -121,7 +122,7 @@ __device__ __forceinline__ void dda_arm(RaySlot2& r, float dx, float dy, float d
     // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
     if (dx != dx || dy != dy || dz != dz || !ok) { r.nk = 1u | PX_SPECIAL << 16; r.tracing = false; }
     if (LRZ && __builtin_expect(r.tracing && (r.ux < 0.0f || r.uy < 0.0f || r.uz < 0.0f), 0))   // rare (origin outside the region): see dda_advance
-        dda_advance<LOGR, LRZ, COUNT, true>(r, dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border, s_swz);
+        dda_advance<LOGR, LRZ, COUNT, true>(r, DIRECT ? (uint32_t)sc.mine[r.vox] : dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border, s_swz);
 }
 
 // Exact counters of one finished ray (the counting build's share of SURVEY 8d's integers).

@@ -1,0 +1,346 @@
+// rt_frame.hip — k_frame: a whole frame in ONE launch, for frames with little work (round 4).
+//
+// The reference only ever renders 1024 x 1024 pixels with one sample and two levels (src/render/constants.rs:9-10, dispatch
+// pipeline.rs:44-45,86-90): two million rays.  The persistent kernels are built for hundreds of millions — one 1024-thread
+// workgroup per CU that first copies a 128 KiB nibble map into LDS, a prepass that writes a worklist, a path kernel that deals
+// paths out of global cursors 128 at a time, an accumulate launch — and a launch of them costs ~0.14 ms however little it has to
+// do.  k_frame is the opposite trade:
+//
+//   * 256-thread workgroups, ALL resident at once (about four waves per SIMD): nothing persistent, no global cursor, no global
+//     worklist, one barrier; a wave walks 1..4 tiles of 8x8 pixels, chosen so that every workgroup gets the same mix of sky and
+//     terrain (tile i of workgroup g is tile i * ngroups + g);
+//   * no LDS copy of the scene: a step reads its minefield byte straight from the brick-swizzled array (one 64-byte line per 4^3
+//     brick; the wave's rays start next to each other, so L1/L2 serve them) — ONE memory round trip per step where the nibble map
+//     costs two on the mixed bricks near a surface, which is where these short rays live;
+//   * phase A: a tile's 64 primary rays in lockstep (they are coherent), then the five primary-only planes — and the lighting of
+//     sky pixels — for the whole wave at once; the pixels that have paths to walk go, with their primary hit, to a queue in the
+//     workgroup's LDS (ballot-ranked, one LDS atomic per wave and tile);
+//   * phase B: a lane takes a pixel from the queue and walks its paths — all samples one after the other, a level's shadow and
+//     diffuse ray together in two slots (k_persist's machinery: rt_dda.hpp) — parks when a level's rays have ended, and when
+//     `threshold` lanes are parked the wave runs one transition pass for all of them, in which lanes whose pixel is finished take
+//     the next one of the queue.  (One tile per wave and no queue — a wave's lanes idle until the tile's longest path has ended —
+//     had 20 % of the slot-lanes of a step in flight and 410 K wave-steps on the reference's frame; the queue: 324 K.)  A
+//     pixel's samples are summed in sample order in registers (0 + l1 + l2 + ...: k_accumulate_paths' arithmetic), so there are
+//     no light records and no accumulate launch, and the lane stores the pixel's lighting itself.
+//
+// Values are those of raytrace.comp under the rt_math.h contract; planes and exact counters equal the oracle's (cached
+// primaries: the primary ray reads no noise, :306-320, and is traced once per pixel).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "rt_dda.hpp"
+#include "rt_device.hpp"
+#include "rt_kernels.hpp"
+
+namespace rtd {
+
+constexpr uint32_t kFrameLdsStack = 7;   // albedo-stack levels per lane in LDS: frames up to depth 8
+constexpr uint32_t kFrameMaxTilesPerWave = 4;   // sizes the workgroup's pixel queue in LDS (16 bytes per pixel)
+
+#ifndef RT_FRAME_WAVES_PER_SIMD
+#define RT_FRAME_WAVES_PER_SIMD 5
+#endif
+template <int LOGR, bool LRZ, bool COUNT>
+__global__ __launch_bounds__(256, RT_FRAME_WAVES_PER_SIMD) void k_frame(Scene sc, Frame f, Planes pl, FrameArgs a) {
+    __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
+    __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];   // swizzle tables (rt_dda.hpp)
+    __shared__ uint32_t s_stack[kFrameLdsStack][256];   // packed material of surface j+1 at level j, per lane
+    __shared__ float4 s_queue[kFrameMaxTilesPerWave * 256];   // the workgroup's non-sky pixels: primary hit, and face id << 28 | local pixel
+    __shared__ uint32_t s_qtail, s_qhead;
+    if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
+    if (threadIdx.x == 0u) { s_qtail = 0u; s_qhead = 0u; }
+    if (dda_uses_swz<LOGR, LRZ>()) dda_fill_swz(s_swz, threadIdx.x, 256u);
+    __syncthreads();
+
+    constexpr int R = 1 << LOGR, LB = LOGR - 2;
+    const float half = (float)R / 2;
+    const uint32_t lane = threadIdx.x & 63u, wiw = threadIdx.x >> 6;
+    const vec3 sunlight = ld3(f.sunlight);
+    const uint32_t D = (uint32_t)f.depth;
+
+    unsigned long long c_prim = 0, c_shadow = 0, c_dif = 0, c_border = 0, c_noise = 0, c_pix = 0;
+    unsigned long long d_a = 0, d_b = 0, d_pass = 0, d_pl = 0, d_sl = 0, d_fl = 0;   // wave-uniform structure statistics (counting build, RT_DEBUG_STATS)
+#ifdef RT_DIAG_FRAME_TIMES   // diagnostic build (tools/variant.sh): per-wave start / end on the 100 MHz clock, shipped arithmetic otherwise
+    constexpr bool kTimes = true;
+#else
+    constexpr bool kTimes = COUNT;
+#endif
+    const unsigned long long t_start = kTimes ? wall_clock64() : 0ull;
+    unsigned long long t_mid = 0;
+    RayTally tl;
+    auto advance = [&](RaySlot2& r, uint32_t step) { dda_advance<LOGR, LRZ, COUNT, false>(r, step, f, half, c_border, s_swz); };
+
+    RaySlot2 S, F;
+    S.px = S.py = S.pz = S.ndx = S.ndy = S.lx = S.ly = S.lz = S.ux = S.uy = S.uz = 0.0f; S.ndz = -1.0f;
+    S.vox = S.cidx = 0u; S.nk = PX_HIT << 16; S.axis = 2u;
+    S.tracing = false; S.valid = true; S.fresh_invalid = false;
+    F = S;
+
+    // ---- phase A: the primary rays (:296-320) of this wave's tiles, a tile at a time in lockstep -----------------------------
+    // Tile i of workgroup g is local tile i * ngroups + g: a workgroup's tiles are spread evenly over the image (every workgroup
+    // gets the same mix of sky and terrain — all workgroups are resident at once, nobody can take work from a neighbour), and
+    // neighbouring workgroups walk neighbouring tiles at the same time.
+    for (uint32_t j = 0; j < a.tiles_per_wave; j++) {
+        const uint32_t tile = (j * 4u + wiw) * gridDim.x + blockIdx.x;
+        if (tile >= (uint32_t)f.ntiles_local) break;   // wave-uniform (the tile index grows with j)
+        const uint32_t lp = tile * 64u + lane;
+        const PixelId pix = pixel_of_local(f, lp);
+        vec3 pdir = v3(0, 0, 1);
+        F.nk = PX_HIT << 16; F.axis = 2u;
+        if (pix.inside) {
+            vec3 start;
+            primary_ray(f, pix.px, pix.py, &start, &pdir);
+            const vec3 d = vnormalize(pdir);                                                          // raytrace.comp:83
+            F.lx = 1.0f / rtm_abs(d.x); F.ly = 1.0f / rtm_abs(d.y); F.lz = 1.0f / rtm_abs(d.z);       // :88
+            int ix, iy, iz;
+            const bool ok = wrap_texel(start, (float)R, &ix, &iy, &iz);
+            dda_arm<LOGR, LRZ, COUNT, true>(F, d.x, d.y, d.z, start.x, start.y, start.z, ok, swizzled_index(ix, iy, iz, LB), 0u, f, half,
+                                            nullptr, sc, c_border, s_swz);
+        }
+        while (__ballot(F.tracing)) {
+            if (COUNT) { d_a++; d_fl += (uint32_t)__popcll(__ballot(F.tracing)); }
+            if (F.tracing) advance(F, sc.mine[F.vox]);
+        }
+        bool queue = false;
+        float hx = 0, hy = 0, hz = 0;
+        uint32_t nrm = 0;
+        if (pix.inside) {
+            const uint32_t kind = r2_kind(F);
+            const bool air = kind == PX_AIR;
+            nrm = F.axis == 0 ? (F.ndx < 0.0f ? 1u : 0u) : (F.axis == 1 ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
+            uint32_t material = 0;
+            if (kind == PX_HIT && (LRZ || F.valid)) material = sc.mat[F.vox];   // the hit texel is the texel of the last fetch (:150-154)
+            hx = F.px; hy = F.py; hz = F.pz;
+            if (kind == PX_SPECIAL) { hx = hy = hz = __builtin_nanf(""); }
+            const float off = 0.001f;                                           // :166-180
+            if (nrm == 0) hx += off; else if (nrm == 1) hx -= off;
+            else if (nrm == 2) hy += off; else if (nrm == 3) hy -= off;
+            else if (nrm == 4) hz += off; else hz -= off;
+            if (COUNT) { c_prim++; c_pix++; dda_tally<LOGR>(F, tl); }
+            store_primary_planes(pl, pix.out_index, f, pdir, air, nrm, material, v3(hx, hy, hz));
+            if (air || D < 1u) {
+                // every sample of this pixel has the same light (no noise is read): summed spp times like the shader's spp frames would
+                vec3 light = v3(0.0f, 0.0f, 0.0f);
+                if (air) light = sample_sky(pdir, ld3(f.sunangle), sunlight, true);                    // raytrace.comp:321-322
+                vec3 sum = v3(0.0f, 0.0f, 0.0f);
+                for (int s = 0; s < f.spp; s++) sum = vadd(sum, light);
+                store_lighting(pl, pix.out_index, sum, f.spp);
+            } else {
+                queue = true;
+            }
+        }
+        // the tile's pixels that have paths to walk go to the workgroup's queue: ballot-ranked slots, one LDS atomic per wave and tile
+        const uint64_t m = __ballot(queue);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0u) base = atomicAdd(&s_qtail, (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (queue) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                s_queue[base + rank] = make_float4(hx, hy, hz, __uint_as_float((nrm << 28) | lp));
+            }
+        }
+    }
+    F.tracing = false;
+    if (kTimes) t_mid = wall_clock64();
+    __syncthreads();   // the queue is complete
+    const uint32_t qtotal = s_qtail;
+
+    // ---- phase B: the paths of the workgroup's non-sky pixels ----------------------------------------------------------------
+    // A lane takes a pixel from the queue, walks all its samples (sum in registers, sample order), stores the pixel's lighting and
+    // takes the next pixel; lanes are refilled in the transition pass, ballot-ranked, one LDS atomic per wave and pass.
+    if (qtotal != 0u) {
+        const uint32_t threshold = a.threshold;
+        const uint32_t spp = (uint32_t)f.spp;
+        bool active = false, dry = false;   // active: the lane holds a pixel; dry (wave-uniform): the queue has been handed out
+        float p0x = 0, p0y = 0, p0z = 0;    // the pixel's primary hit: the surface every sample starts from
+        uint32_t n0lp = 0;                  // its face id << 28 | local pixel
+        uint32_t level = 0, sunbits = 0, samp = 0, nvtex = 0;   // level 0: the lane's next sample has not begun
+        uint32_t dif_entry = 0xFFFFFFFFu, sun_entry = 0xFFFFFFFFu;   // table entries held by F's / S's direction registers
+        float sumx = 0.0f, sumy = 0.0f, sumz = 0.0f;
+        for (;;) {
+            const uint64_t m_busy = __ballot(S.tracing || F.tracing);
+            const uint64_t m_wait = __ballot(!(S.tracing || F.tracing) && (active || !dry));
+            const uint32_t n_busy = (uint32_t)__popcll(m_busy), n_wait = (uint32_t)__popcll(m_wait);
+            if (n_wait < threshold && n_busy != 0u) {
+                // step loop: both rays of a lane together (their fetches overlap), until enough further lanes have parked
+                const uint32_t need = threshold - n_wait;
+                const uint32_t target = n_busy > need ? n_busy - need : 0u;
+                do {
+                    if (COUNT) { d_b++; d_sl += (uint32_t)__popcll(__ballot(S.tracing)); d_fl += (uint32_t)__popcll(__ballot(F.tracing)); }
+                    uint32_t stS = 0, stF = 0;
+                    if (S.tracing) stS = sc.mine[S.vox];      // :106 for a fresh ray, :137 otherwise
+                    if (F.tracing) stF = sc.mine[F.vox];
+                    if (S.tracing) advance(S, stS);
+                    if (F.tracing) advance(F, stF);
+                } while ((uint32_t)__popcll(__ballot(S.tracing || F.tracing)) > target);
+            } else if (n_wait == 0u) {
+                break;   // nothing in flight, nothing parked, nothing left to take
+            }
+            // ---- transition pass: lanes whose level has ended, lanes without a pixel -----------------------------------------
+            const bool mine = !(S.tracing || F.tracing) && active;
+            if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); }
+            bool begin_level = false, new_sample = false;
+            float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
+            uint32_t snormal = 0;
+            if (mine) {
+                // diffuse result: the hit texel is the texel of the last fetch, so the material is mat[vox] (:150-154); the position
+                // gets the 0.001 face offset (:166-180)
+                const uint32_t fkind = r2_kind(F);
+                const bool air = fkind == PX_AIR;
+                const uint32_t nrm = F.axis == 0 ? (F.ndx < 0.0f ? 1u : 0u) : (F.axis == 1 ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
+                if (COUNT) { dda_tally<LOGR>(F, tl); dda_tally<LOGR>(S, tl); }
+                if (r2_kind(S) == PX_AIR) sunbits |= 1u << (level - 1);                      // :326-328 / :338-340
+                if (air || level == D) {
+                    vec3 sky = v3(0, 0, 0);
+                    if (air) { const float4 t = a.dif_lut[dif_entry + 3u]; sky = v3(t.x, t.y, t.z); }   // :331-332 / :343-345, tabulated
+                    // L_j = [sun_j] S + L_{j+1} * albedo_{j+1} + emission, innermost first (raytrace.comp:346-348)
+                    vec3 L = v3(0.0f, 0.0f, 0.0f);
+                    if (sunbits >> (level - 1) & 1u) L = vadd(L, sunlight);
+                    if (air) L = vadd(L, sky);
+                    for (uint32_t j = level - 1; j >= 1u; j--) {
+                        const uint32_t pm = s_stack[j - 1][threadIdx.x];
+                        vec3 light2 = vmul(L, v3(s_albedo[pm >> 14 & 0x7Fu], s_albedo[pm >> 7 & 0x7Fu], s_albedo[pm & 0x7Fu]));
+                        light2 = vadd(light2, v3(0.0f, 0.0f, 0.0f));      // + dif.emission, always vec3(0) (:155)
+                        vec3 acc = v3(0.0f, 0.0f, 0.0f);
+                        if (sunbits >> (j - 1) & 1u) acc = vadd(acc, sunlight);
+                        L = vadd(acc, light2);
+                    }
+                    const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
+                    sumx = sumx + light.x; sumy = sumy + light.y; sumz = sumz + light.z;   // samples in order (k_accumulate_paths)
+                    samp++;
+                    if (samp < spp) new_sample = true;
+                    else {
+                        const PixelId pix = pixel_of_local(f, n0lp & 0x0FFFFFFFu);
+                        store_lighting(pl, pix.out_index, v3(sumx, sumy, sumz), f.spp);
+                        active = false;
+                    }
+                } else {
+                    uint32_t material = 0;
+                    if (fkind == PX_HIT && (LRZ || F.valid)) material = sc.mat[F.vox];
+                    s_stack[level - 1][threadIdx.x] = material;   // albedo of surface level+1
+                    float hx = F.px, hy = F.py, hz = F.pz;
+                    if (fkind == PX_SPECIAL) { hx = hy = hz = __builtin_nanf(""); }
+                    const float off = 0.001f;
+                    if (nrm == 0) hx += off; else if (nrm == 1) hx -= off;
+                    else if (nrm == 2) hy += off; else if (nrm == 3) hy -= off;
+                    else if (nrm == 4) hz += off; else hz -= off;
+                    sfx = hx; sfy = hy; sfz = hz; snormal = nrm;
+                    level++; begin_level = true;
+                }
+            }
+            // lanes without a pixel take the next ones of the queue
+            if (!dry) {
+                const uint64_t want = __ballot(!active);
+                if (want) {
+                    uint32_t base = 0;
+                    if (lane == 0u) base = atomicAdd(&s_qhead, (uint32_t)__popcll(want));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const uint32_t avail = base < qtotal ? qtotal - base : 0u;
+                    if (avail < (uint32_t)__popcll(want)) dry = true;   // (the head only grows: nothing will be left for a later pass either)
+                    if (!active) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                        if (rank < avail) {
+                            const float4 e = s_queue[base + rank];
+                            p0x = e.x; p0y = e.y; p0z = e.z; n0lp = __float_as_uint(e.w);
+                            active = true; samp = 0; sumx = sumy = sumz = 0.0f;
+                            new_sample = true;
+                        }
+                    }
+                }
+            }
+            if (new_sample) {
+                // noise_offset of this sample (:298-304) and its noise_value texel (:324, :336).  The bytes are exact integers in
+                // float and the per-level offset (level-1) * 2/512 never reaches the next texel, so one integer lookup serves
+                // every level (tests/test_math_contract.py::test_noise_value_texel_is_level_independent)
+                const PixelId pix = pixel_of_local(f, n0lp & 0x0FFFFFFFu);
+                const uint32_t wgx8 = owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE, wgy8 = owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE;
+                const uint32_t seed = (f.seed + samp) % (uint32_t)RT_NOISE_BYTES;
+                const uint32_t by = seed / RT_NOISE_SIZE;
+                const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
+                const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
+                nvtex = sc.noise[ty * RT_NOISE_SIZE + tx];
+                sfx = p0x; sfy = p0y; sfz = p0z; snormal = n0lp >> 28;
+                level = 1; sunbits = 0; begin_level = true;
+            }
+            // both rays of a level (:324-330 / :336-342): shadow ray and diffuse ray from the tables
+            if (begin_level) {
+                if (COUNT) { c_noise++; c_shadow++; c_dif++; }
+                int ix, iy, iz;
+                const bool ok = wrap_texel(v3(sfx, sfy, sfz), (float)R, &ix, &iy, &iz);
+                const uint32_t vox0 = swizzled_index(ix, iy, iz, LB);
+                // stepping never touches a slot's direction registers: the shadow entry depends on the sample's noise texel only
+                // (same for all its levels, Q5) and the diffuse entry repeats whenever the next surface has the same face
+                const uint32_t se = nvtex & 0xFFFFu;
+                if (se != sun_entry) {
+                    const float4 sd = a.sun_lut[2u * se], sl = a.sun_lut[2u * se + 1u];
+                    S.ndx = -sd.x; S.ndy = -sd.y; S.ndz = -sd.z; S.lx = sl.x; S.ly = sl.y; S.lz = sl.z;
+                    sun_entry = se;
+                }
+                const uint32_t di = 4u * ((snormal << 16) | se);
+                if (di != dif_entry) {
+                    const float4 d2 = a.dif_lut[di + 1u], dl = a.dif_lut[di + 2u];
+                    F.ndx = -d2.x; F.ndy = -d2.y; F.ndz = -d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
+                    dif_entry = di;
+                }
+                dda_arm<LOGR, LRZ, COUNT, true>(S, -S.ndx, -S.ndy, -S.ndz, sfx, sfy, sfz, ok, vox0, 0u, f, half, nullptr, sc, c_border, s_swz);
+                dda_arm<LOGR, LRZ, COUNT, true>(F, -F.ndx, -F.ndy, -F.ndz, sfx, sfy, sfz, ok, vox0, 0u, f, half, nullptr, sc, c_border, s_swz);
+            }
+        }
+    }
+    if (kTimes && a.dbg_waves && lane == 0u) {   // RT_DEBUG_WAVE_DUMP: (start, end of phase A, end, phase-A steps | phase-B steps << 16 | passes << 32) per wave
+        unsigned long long* w = a.dbg_waves + 4u * (blockIdx.x * 4u + wiw);
+        w[0] = t_start; w[1] = t_mid; w[2] = wall_clock64(); w[3] = d_a | d_b << 16 | d_pass << 32;
+    }
+    if (COUNT) {
+        DevCounters* cn = a.counters;
+        const unsigned long long rays = c_prim + c_shadow + c_dif;
+        c_border += tl.border;
+        wave_add(&cn->rays, rays); wave_add(&cn->rays_primary, c_prim); wave_add(&cn->rays_shadow, c_shadow);
+        wave_add(&cn->rays_diffuse, c_dif); wave_add(&cn->iterations, tl.iter); wave_add(&cn->minefield_fetches, rays + tl.iter);
+        wave_add(&cn->hits, tl.hits); wave_add(&cn->material_fetches, tl.hits); wave_add(&cn->sky_exits, tl.sky);
+        wave_add(&cn->limit_exits, tl.limit); wave_add(&cn->border_fetches, c_border); wave_add(&cn->noise_fetches, c_noise);
+        wave_add(&cn->pixels, c_pix);
+        if (lane == 0) {   // dbg_*: phase-A steps in s_execs, phase-B steps in loop_iters, waves with a phase B in f_execs
+            atomicAdd(&cn->dbg_s_execs, d_a); atomicAdd(&cn->dbg_loop_iters, d_b); atomicAdd(&cn->dbg_passes, d_pass);
+            atomicAdd(&cn->dbg_pass_lanes, d_pl); atomicAdd(&cn->dbg_s_lanes, d_sl); atomicAdd(&cn->dbg_f_lanes, d_fl);
+            if (d_pass) atomicAdd(&cn->dbg_f_execs, 1ull);
+            atomicMax(&cn->dbg_sky_lanes, d_a + d_b);   // longest wave, in steps
+        }
+    }
+}
+
+bool launch_frame_ok(const Frame& f) { return f.depth <= (int)kFrameLdsStack + 1 && f.logr >= 8 && f.logr <= 10; }
+
+template <int LOGR>
+static void launch_frame_logr(const Scene& sc, const Frame& f, const Planes& pl, const FrameArgs& a, bool count, dim3 grid, hipStream_t st) {
+    const dim3 block(256);
+    if (f.lr_zero != 0) {
+        if (count) hipLaunchKernelGGL((k_frame<LOGR, true, true>), grid, block, 0, st, sc, f, pl, a);
+        else hipLaunchKernelGGL((k_frame<LOGR, true, false>), grid, block, 0, st, sc, f, pl, a);
+    } else {
+        if (count) hipLaunchKernelGGL((k_frame<LOGR, false, true>), grid, block, 0, st, sc, f, pl, a);
+        else hipLaunchKernelGGL((k_frame<LOGR, false, false>), grid, block, 0, st, sc, f, pl, a);
+    }
+}
+
+hipError_t launch_frame(const Scene& sc, const Frame& f, const Planes& pl, FrameArgs a, bool count, int num_cus, hipStream_t st) {
+    if (f.ntiles_local <= 0) return hipSuccess;
+    if (!launch_frame_ok(f)) return hipErrorInvalidValue;
+    // Tiles per wave: as many as it takes for ALL workgroups to be resident at once with about four waves per SIMD (a wave then
+    // refills its lanes from the workgroup's queue instead of leaving them idle while the tile's longest path finishes, and no
+    // workgroup starts late) — one for frames of up to 4 x 4 x CUs tiles (512 x 512 pixels on 256 CUs), at most kFrameMaxTilesPerWave.
+    const uint32_t ntiles = (uint32_t)f.ntiles_local, resident = 16u * (uint32_t)(num_cus > 0 ? num_cus : 256);
+    uint32_t k = a.tiles_per_wave ? a.tiles_per_wave : (ntiles + resident - 1u) / resident;
+    if (k < 1u) k = 1u;
+    if (k > kFrameMaxTilesPerWave) k = kFrameMaxTilesPerWave;
+    a.tiles_per_wave = k;
+    const dim3 grid((ntiles + 4u * k - 1u) / (4u * k));   // four waves per workgroup
+    if (a.threshold < 1u || a.threshold > 64u) a.threshold = 32u;
+    if (f.logr == 8) launch_frame_logr<8>(sc, f, pl, a, count, grid, st);
+    else if (f.logr == 9) launch_frame_logr<9>(sc, f, pl, a, count, grid, st);
+    else launch_frame_logr<10>(sc, f, pl, a, count, grid, st);
+    return hipGetLastError();
+}
+
+}  // namespace rtd

@@ -84,6 +84,17 @@ struct PersistArgs {
     PathLight* pl;              // [nsamples * nwork] light of each path (one 12-byte store per path)
     DevCounters* counters;
 };
+// k_frame (rt_frame.hip): the whole frame in one launch — primary rays, every sample's paths, the planes — for frames with little work
+struct FrameArgs {
+    uint32_t threshold;         // parked lanes per wave that trigger a transition pass (1..64; 0 = the default)
+    uint32_t tiles_per_wave;    // 0 = chosen by launch_frame from the frame's size (RT_FRAME_TILES overrides)
+    const float4* sun_lut;      // as PersistArgs
+    const float4* dif_lut;
+    DevCounters* counters;
+    unsigned long long* dbg_waves;   // counting build, diagnostics: four words per tile (null: none)
+};
+bool launch_frame_ok(const Frame& f);   // does k_frame cover this frame (depth <= 8)?
+hipError_t launch_frame(const Scene& sc, const Frame& f, const Planes& pl, FrameArgs a, bool count, int num_cus, hipStream_t st);
 hipError_t launch_accumulate_paths(const Frame& f, const Planes& planes, const PathLight* pl, const uint32_t* worklist,
                                    const uint32_t* wl_count, uint32_t npix_pad, uint32_t nsamples, bool first_batch, bool last_batch,
                                    bool cache, bool stream, float4* acc, hipStream_t st);

@@ -37,7 +37,7 @@ def _ptrs(ctx):
     return {b: ctx.device_ptr(b) for b in range(abi.RT_BUF_FINAL_BGRA8)}
 
 
-@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PATHS, abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_DEFAULT])
+@pytest.mark.parametrize("kernel", [abi.RT_KERNEL_PATHS, abi.RT_KERNEL_PERSISTENT, abi.RT_KERNEL_DEFAULT, abi.RT_KERNEL_FRAME])
 @pytest.mark.parametrize("batch", [None, "2"])
 def test_two_frames_in_flight_are_the_frames_of_their_own_uniforms(procedural_region, blue_noise, kernel, batch, monkeypatch):
     """Six frames with six different cameras, seeds and TWO sun angles (the per-frame tables are rebuilt between frames that are
@@ -191,7 +191,8 @@ def test_one_sample_frames_store_their_lighting_in_the_path_kernel(procedural_re
 
 def test_default_kernel_switches_to_k_paths_for_one_sample_frames_of_three_million_pixels(procedural_region, blue_noise):
     """RT_KERNEL_DEFAULT runs launches of >= 3 M pixel-samples on k_paths: a 2304 x 1408 one-sample frame (3.24 M pixels) is on
-    k_paths' direct path, a 1024 x 1024 one on k_persist's; two 8-row bands of the big frame against the oracle."""
+    k_paths' direct path, a 1920 x 1080 one on k_persist's (below 1.5 M pixels k_frame takes over: tests/test_gpu_frame_kernel.py); two
+    8-row bands of the big frame against the oracle."""
     mats, mine = procedural_region
     W, H, depth = 2304, 1408, 2
     u = po.camera_uniforms((-30.0, -128.0, 100.0), np.pi / 2, -0.1, 0.3, 17)
@@ -208,7 +209,7 @@ def test_default_kernel_switches_to_k_paths_for_one_sample_frames_of_three_milli
         band, _ = po.render(mats, mine, blue_noise, u, W, H, 1, depth, rows=(y0, y0 + 8))
         for name in band:
             assert np.array_equal(got[name][y0:y0 + 8], band[name][y0:y0 + 8], equal_nan=True), (name, y0)
-    with render.Context(render.make_config(1024, 1024, spp=1, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY)) as ctx:
+    with render.Context(render.make_config(1920, 1080, spp=1, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY)) as ctx:
         ctx.upload_world(mats, mine)
         ctx.upload_noise(blue_noise)
         ctx.draw_frame(u)
