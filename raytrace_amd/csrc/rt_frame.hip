@@ -37,19 +37,23 @@ namespace rtd {
 constexpr uint32_t kFrameLdsStack = 7;   // albedo-stack levels per lane in LDS: frames up to depth 8
 constexpr uint32_t kFrameMaxTilesPerWave = 4;   // sizes the workgroup's pixel queue in LDS (16 bytes per pixel)
 
+#ifndef RT_FRAME_WG_WAVES
+#define RT_FRAME_WG_WAVES 4      // waves per workgroup: they share the pixel queue
+#endif
+constexpr uint32_t kFrameWgWaves = RT_FRAME_WG_WAVES, kFrameWg = 64u * kFrameWgWaves;
 #ifndef RT_FRAME_WAVES_PER_SIMD
 #define RT_FRAME_WAVES_PER_SIMD 5
 #endif
 template <int LOGR, bool LRZ, bool COUNT>
-__global__ __launch_bounds__(256, RT_FRAME_WAVES_PER_SIMD) void k_frame(Scene sc, Frame f, Planes pl, FrameArgs a) {
+__global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Scene sc, Frame f, Planes pl, FrameArgs a) {
     __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
     __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];   // swizzle tables (rt_dda.hpp)
-    __shared__ uint32_t s_stack[kFrameLdsStack][256];   // packed material of surface j+1 at level j, per lane
-    __shared__ float4 s_queue[kFrameMaxTilesPerWave * 256];   // the workgroup's non-sky pixels: primary hit, and face id << 28 | local pixel
+    __shared__ uint32_t s_stack[kFrameLdsStack][kFrameWg];   // packed material of surface j+1 at level j, per lane
+    __shared__ float4 s_queue[kFrameMaxTilesPerWave * kFrameWg];   // the workgroup's non-sky pixels: primary hit, and face id << 28 | local pixel
     __shared__ uint32_t s_qtail, s_qhead;
     if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
     if (threadIdx.x == 0u) { s_qtail = 0u; s_qhead = 0u; }
-    if (dda_uses_swz<LOGR, LRZ>()) dda_fill_swz(s_swz, threadIdx.x, 256u);
+    if (dda_uses_swz<LOGR, LRZ>()) dda_fill_swz(s_swz, threadIdx.x, kFrameWg);
     __syncthreads();
 
     constexpr int R = 1 << LOGR, LB = LOGR - 2;
@@ -76,47 +80,44 @@ __global__ __launch_bounds__(256, RT_FRAME_WAVES_PER_SIMD) void k_frame(Scene sc
     S.tracing = false; S.valid = true; S.fresh_invalid = false;
     F = S;
 
-    // ---- phase A: the primary rays (:296-320) of this wave's tiles, a tile at a time in lockstep -----------------------------
+    // ---- phase A: the primary rays (:296-320) of this wave's tiles, in lockstep ------------------------------------------------
     // Tile i of workgroup g is local tile i * ngroups + g: a workgroup's tiles are spread evenly over the image (every workgroup
     // gets the same mix of sky and terrain — all workgroups are resident at once, nobody can take work from a neighbour), and
     // neighbouring workgroups walk neighbouring tiles at the same time.
-    for (uint32_t j = 0; j < a.tiles_per_wave; j++) {
-        const uint32_t tile = (j * 4u + wiw) * gridDim.x + blockIdx.x;
-        if (tile >= (uint32_t)f.ntiles_local) break;   // wave-uniform (the tile index grows with j)
-        const uint32_t lp = tile * 64u + lane;
-        const PixelId pix = pixel_of_local(f, lp);
-        vec3 pdir = v3(0, 0, 1);
-        F.nk = PX_HIT << 16; F.axis = 2u;
+    // Two tiles at a time, one in each ray slot: a lone primary ray leaves the wave waiting for one byte per step, two independent
+    // fetch chains halve the steps of the phase (RT_FRAME_PAIR_A=0: one tile at a time).
+    auto arm_primary = [&](RaySlot2& r, const PixelId& pix, vec3& pdir) {
+        pdir = v3(0, 0, 1);
+        r.nk = PX_HIT << 16; r.axis = 2u;
         if (pix.inside) {
             vec3 start;
             primary_ray(f, pix.px, pix.py, &start, &pdir);
             const vec3 d = vnormalize(pdir);                                                          // raytrace.comp:83
-            F.lx = 1.0f / rtm_abs(d.x); F.ly = 1.0f / rtm_abs(d.y); F.lz = 1.0f / rtm_abs(d.z);       // :88
+            r.lx = 1.0f / rtm_abs(d.x); r.ly = 1.0f / rtm_abs(d.y); r.lz = 1.0f / rtm_abs(d.z);       // :88
             int ix, iy, iz;
             const bool ok = wrap_texel(start, (float)R, &ix, &iy, &iz);
-            dda_arm<LOGR, LRZ, COUNT, true>(F, d.x, d.y, d.z, start.x, start.y, start.z, ok, swizzled_index(ix, iy, iz, LB), 0u, f, half,
+            dda_arm<LOGR, LRZ, COUNT, true>(r, d.x, d.y, d.z, start.x, start.y, start.z, ok, swizzled_index(ix, iy, iz, LB), 0u, f, half,
                                             nullptr, sc, c_border, s_swz);
         }
-        while (__ballot(F.tracing)) {
-            if (COUNT) { d_a++; d_fl += (uint32_t)__popcll(__ballot(F.tracing)); }
-            if (F.tracing) advance(F, sc.mine[F.vox]);
-        }
+    };
+    // the tile's planes, the lighting of its sky pixels, and its other pixels into the workgroup's queue
+    auto finish_primary = [&](const RaySlot2& r, const PixelId& pix, const vec3& pdir, uint32_t lp) {
         bool queue = false;
         float hx = 0, hy = 0, hz = 0;
         uint32_t nrm = 0;
         if (pix.inside) {
-            const uint32_t kind = r2_kind(F);
+            const uint32_t kind = r2_kind(r);
             const bool air = kind == PX_AIR;
-            nrm = F.axis == 0 ? (F.ndx < 0.0f ? 1u : 0u) : (F.axis == 1 ? (F.ndy < 0.0f ? 3u : 2u) : (F.ndz < 0.0f ? 5u : 4u));
+            nrm = r.axis == 0 ? (r.ndx < 0.0f ? 1u : 0u) : (r.axis == 1 ? (r.ndy < 0.0f ? 3u : 2u) : (r.ndz < 0.0f ? 5u : 4u));
             uint32_t material = 0;
-            if (kind == PX_HIT && (LRZ || F.valid)) material = sc.mat[F.vox];   // the hit texel is the texel of the last fetch (:150-154)
-            hx = F.px; hy = F.py; hz = F.pz;
+            if (kind == PX_HIT && (LRZ || r.valid)) material = sc.mat[r.vox];   // the hit texel is the texel of the last fetch (:150-154)
+            hx = r.px; hy = r.py; hz = r.pz;
             if (kind == PX_SPECIAL) { hx = hy = hz = __builtin_nanf(""); }
             const float off = 0.001f;                                           // :166-180
             if (nrm == 0) hx += off; else if (nrm == 1) hx -= off;
             else if (nrm == 2) hy += off; else if (nrm == 3) hy -= off;
             else if (nrm == 4) hz += off; else hz -= off;
-            if (COUNT) { c_prim++; c_pix++; dda_tally<LOGR>(F, tl); }
+            if (COUNT) { c_prim++; c_pix++; dda_tally<LOGR>(r, tl); }
             store_primary_planes(pl, pix.out_index, f, pdir, air, nrm, material, v3(hx, hy, hz));
             if (air || D < 1u) {
                 // every sample of this pixel has the same light (no noise is read): summed spp times like the shader's spp frames would
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256, RT_FRAME_WAVES_PER_SIMD) void k_frame(Scene sc
                 queue = true;
             }
         }
-        // the tile's pixels that have paths to walk go to the workgroup's queue: ballot-ranked slots, one LDS atomic per wave and tile
+        // ballot-ranked slots, one LDS atomic per wave and tile
         const uint64_t m = __ballot(queue);
         if (m) {
             uint32_t base = 0;
@@ -140,7 +141,30 @@ __global__ __launch_bounds__(256, RT_FRAME_WAVES_PER_SIMD) void k_frame(Scene sc
                 s_queue[base + rank] = make_float4(hx, hy, hz, __uint_as_float((nrm << 28) | lp));
             }
         }
+    };
+    const uint32_t jstep = a.pair_a ? 2u : 1u;
+    for (uint32_t j = 0; j < a.tiles_per_wave; j += jstep) {
+        const uint32_t tile0 = (j * kFrameWgWaves + wiw) * gridDim.x + blockIdx.x, tile1 = ((j + 1u) * kFrameWgWaves + wiw) * gridDim.x + blockIdx.x;
+        if (tile0 >= (uint32_t)f.ntiles_local) break;   // wave-uniform (the tile index grows with j)
+        const bool two = a.pair_a && j + 1u < a.tiles_per_wave && tile1 < (uint32_t)f.ntiles_local;
+        const uint32_t lp0 = tile0 * 64u + lane, lp1 = tile1 * 64u + lane;
+        const PixelId pix0 = pixel_of_local(f, lp0);
+        PixelId pix1 = pix0;
+        vec3 pdir0, pdir1 = v3(0, 0, 1);
+        arm_primary(F, pix0, pdir0);
+        if (two) { pix1 = pixel_of_local(f, lp1); arm_primary(S, pix1, pdir1); }
+        while (__ballot(F.tracing || S.tracing)) {
+            if (COUNT) { d_a++; d_fl += (uint32_t)__popcll(__ballot(F.tracing)) + (uint32_t)__popcll(__ballot(S.tracing)); }
+            uint32_t stS = 0, stF = 0;
+            if (F.tracing) stF = sc.mine[F.vox];
+            if (S.tracing) stS = sc.mine[S.vox];
+            if (F.tracing) advance(F, stF);
+            if (S.tracing) advance(S, stS);
+        }
+        finish_primary(F, pix0, pdir0, lp0);
+        if (two) finish_primary(S, pix1, pdir1, lp1);
     }
+    S.tracing = false;
     F.tracing = false;
     if (kTimes) t_mid = wall_clock64();
     __syncthreads();   // the queue is complete
@@ -289,7 +313,7 @@ __global__ __launch_bounds__(256, RT_FRAME_WAVES_PER_SIMD) void k_frame(Scene sc
         }
     }
     if (kTimes && a.dbg_waves && lane == 0u) {   // RT_DEBUG_WAVE_DUMP: (start, end of phase A, end, phase-A steps | phase-B steps << 16 | passes << 32) per wave
-        unsigned long long* w = a.dbg_waves + 4u * (blockIdx.x * 4u + wiw);
+        unsigned long long* w = a.dbg_waves + 4u * (blockIdx.x * kFrameWgWaves + wiw);
         w[0] = t_start; w[1] = t_mid; w[2] = wall_clock64(); w[3] = d_a | d_b << 16 | d_pass << 32;
     }
     if (COUNT) {
@@ -314,7 +338,7 @@ bool launch_frame_ok(const Frame& f) { return f.depth <= (int)kFrameLdsStack + 1
 
 template <int LOGR>
 static void launch_frame_logr(const Scene& sc, const Frame& f, const Planes& pl, const FrameArgs& a, bool count, dim3 grid, hipStream_t st) {
-    const dim3 block(256);
+    const dim3 block(kFrameWg);
     if (f.lr_zero != 0) {
         if (count) hipLaunchKernelGGL((k_frame<LOGR, true, true>), grid, block, 0, st, sc, f, pl, a);
         else hipLaunchKernelGGL((k_frame<LOGR, true, false>), grid, block, 0, st, sc, f, pl, a);
@@ -335,7 +359,9 @@ hipError_t launch_frame(const Scene& sc, const Frame& f, const Planes& pl, Frame
     if (k < 1u) k = 1u;
     if (k > kFrameMaxTilesPerWave) k = kFrameMaxTilesPerWave;
     a.tiles_per_wave = k;
-    const dim3 grid((ntiles + 4u * k - 1u) / (4u * k));   // four waves per workgroup
+    static const bool pair_a = getenv("RT_FRAME_PAIR_A") == nullptr || atoi(getenv("RT_FRAME_PAIR_A")) != 0;
+    a.pair_a = pair_a ? 1u : 0u;
+    const dim3 grid((ntiles + kFrameWgWaves * k - 1u) / (kFrameWgWaves * k));
     if (a.threshold < 1u || a.threshold > 64u) a.threshold = 32u;
     if (f.logr == 8) launch_frame_logr<8>(sc, f, pl, a, count, grid, st);
     else if (f.logr == 9) launch_frame_logr<9>(sc, f, pl, a, count, grid, st);

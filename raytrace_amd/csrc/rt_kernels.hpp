@@ -88,6 +88,7 @@ struct PersistArgs {
 struct FrameArgs {
     uint32_t threshold;         // parked lanes per wave that trigger a transition pass (1..64; 0 = the default)
     uint32_t tiles_per_wave;    // 0 = chosen by launch_frame from the frame's size (RT_FRAME_TILES overrides)
+    uint32_t pair_a;            // set by launch_frame: phase A walks two tiles at a time, one per ray slot (RT_FRAME_PAIR_A=0: one)
     const float4* sun_lut;      // as PersistArgs
     const float4* dif_lut;
     DevCounters* counters;
