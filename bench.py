@@ -31,7 +31,7 @@ import numpy as np  # noqa: E402
 
 COUNTERS_FILE = "r4_counters.json"   # written by tools/pmc_to_json.py on the GPU box (tools/profile_r4.sh)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-KERNEL_NAMES = {"paths": "k_paths", "persistent": "k_persist", "wavefront": "k_trace", "mega": "k_mega"}
+KERNEL_NAMES = {"paths": "k_paths", "persistent": "k_persist", "frame": "k_frame", "wavefront": "k_trace", "mega": "k_mega"}
 
 
 def parse_args():
@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1, help="seed of the frame's first sample (pipeline.rs:201 starts at 1)")
     ap.add_argument("--vary-seed", action="store_true",
                     help="frame i is drawn with seed + i (every step renders a different frame; the hash is the last one's)")
-    ap.add_argument("--kernel", choices=["default", "paths", "persistent", "wavefront", "mega"], default="default")
+    ap.add_argument("--kernel", choices=["default", "paths", "persistent", "frame", "wavefront", "mega"], default="default")
     ap.add_argument("--no-cache-primary", dest="cache_primary", action="store_false",
                     help="re-trace the (seed-independent) primary ray for every sample, like spp reference frames would")
     ap.set_defaults(cache_primary=True)
@@ -179,7 +179,7 @@ def main():
         os.environ.setdefault("RT_RESERVE_CUS", "8")
     reserve_cus = int(os.environ.get("RT_RESERVE_CUS", "0") or 0)
 
-    kernel = {"default": abi.RT_KERNEL_DEFAULT, "paths": abi.RT_KERNEL_PATHS, "persistent": abi.RT_KERNEL_PERSISTENT,
+    kernel = {"default": abi.RT_KERNEL_DEFAULT, "paths": abi.RT_KERNEL_PATHS, "persistent": abi.RT_KERNEL_PERSISTENT, "frame": abi.RT_KERNEL_FRAME,
               "wavefront": abi.RT_KERNEL_WAVEFRONT, "mega": abi.RT_KERNEL_MEGA}[args.kernel]
     xflags = abi.RT_FLAG_CACHE_PRIMARY if args.cache_primary else 0
     if args.frames_in_flight == 2:
@@ -237,13 +237,15 @@ def main():
         cctx.draw_frame(u0)
         cctx.sync()
         # the report names the kernel the frame actually ran on (RT_KERNEL_DEFAULT picks k_paths / k_persist per frame)
-        rec["kernel"] = {abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent",
+        rec["kernel"] = {abi.RT_KERNEL_PATHS: "paths", abi.RT_KERNEL_PERSISTENT: "persistent", abi.RT_KERNEL_FRAME: "frame",
                          abi.RT_KERNEL_WAVEFRONT: "wavefront", abi.RT_KERNEL_MEGA: "mega"}[cctx.kernel_in_use()]
         cn = cctx.counters()
+        cctx_kernel = rec["kernel"]
         cctx.destroy()
         rec["rays"] = cn.rays
         # traversal algorithmic bytes: 1 B per minefield fetch + 4 B per material fetch
-        rec["trace_bytes"] = cn.minefield_fetches + 4 * cn.material_fetches
+        # (k_frame's one launch is the whole frame: primary rays, noise and the G-buffer stores are its algorithmic bytes too)
+        rec["trace_bytes"] = cn.algorithmic_bytes() if cctx_kernel == "frame" else cn.minefield_fetches + 4 * cn.material_fetches
         rec["balg"] = cn.algorithmic_bytes()
         rec["ref_rays"] = cn.rays + (SPP - 1) * cn.pixels if args.cache_primary else cn.rays
         if rec["kernel"] in ("paths", "persistent") and args.cache_primary and D >= 1:

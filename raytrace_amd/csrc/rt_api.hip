@@ -822,7 +822,10 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         }
         hipStream_t tail = st0;
         if (e == hipSuccess && one_launch) {
-            ctx->path_launches++;   // (frames alternate between the lanes' streams like path launches do)
+            // with two frame slots consecutive frames go to the two streams in turn (frame k + 1 starts while frame k's last
+            // workgroups finish); with one slot a frame follows the previous one anyway, and staying on one stream spares the
+            // cross-stream event wait between them
+            if (nsl == 2) ctx->path_launches++;
             rtd::FrameArgs fa{};
             fa.threshold = ctx->frame_threshold; fa.tiles_per_wave = ctx->frame_tiles; fa.sun_lut = ctx->sun_lut; fa.dif_lut = ctx->dif_lut; fa.counters = ctx->d_counters;
             if (getenv("RT_DEBUG_WAVE_DUMP") && (size_t)ctx->ntiles_local * 32u <= (size_t)4 * ctx->num_cus * 1024 * sizeof(uint32_t))

@@ -5,7 +5,8 @@ import csv, glob, hashlib, json, os, re, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = sys.argv[1]
 WORK = {"head": "1920x1080 spp=64 depth=4 region=256", "c5": "3840x2160 spp=1024 depth=8 region=1024",
-        "c4": "3840x2160 spp=256 depth=8 region=256", "c5t": "3840x2160 spp=1024 depth=8 region=1024 pose=terrain"}
+        "c4": "3840x2160 spp=256 depth=8 region=256", "c5t": "3840x2160 spp=1024 depth=8 region=1024 pose=terrain",
+        "ref": "1024x1024 spp=1 depth=2 region=256"}
 SIMDS = 256 * 4
 
 
@@ -55,9 +56,9 @@ for tag, wname in WORK.items():
     per = collections.defaultdict(dict)
     st = stats(os.path.join(prof, tag + "_stats"))
     for (k, full), v in st.items():
-        if re.search(r"k_paths<true|k_persist<\d+, (true|false), true,|k_primary2<\d+, (true|false), true>|k_accumulate_paths<false>", full):
+        if re.search(r"k_paths<true|k_persist<\d+, (true|false), true,|k_primary2<\d+, (true|false), true>|k_frame<\d+, (true|false), true>|k_accumulate_paths<false>", full):
             continue   # counting builds run once outside the timed region
-        if k in ("k_paths", "k_persist", "k_primary2", "k_accumulate_paths"):
+        if k in ("k_paths", "k_persist", "k_frame", "k_primary2", "k_accumulate_paths"):
             per[k]["instantiation"] = full
             per[k]["avg_launch_ms"] = round(v["avg_ns"] / 1e6, 4); per[k]["min_launch_ms"] = round(v["min_ns"] / 1e6, 4); per[k]["launches_profiled"] = v["calls"]
     for sub in ("fetch", "write", "tcc", "sq1", "sq2", "sq3"):

@@ -11,6 +11,7 @@ HEAD_ARGS="--steps 3 --warmup 1 $X"
 HEAD_STATS_ARGS="--steps 10 --warmup 3 $X"   # kernel-trace pass: enough launches that cold ones do not set the average
 C5_ARGS="--region 1024 --width 3840 --height 2160 --spp 1024 --depth 8 --steps 1 --warmup 1 $X"
 C5T_ARGS="$C5_ARGS --pose=-120,-512,160,1.5707964,-0.3 --spp 128"     # the terrain-heavy pose (8.7 x the rays per sample): an eighth of the samples
+REF_ARGS="--width 1024 --height 1024 --spp 1 --depth 2 --steps 50 --warmup 5 $X"    # the reference's own frame: one launch of k_frame
 C4_ARGS="--width 3840 --height 2160 --spp 256 --depth 8 --steps 2 --warmup 1 $X"
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 P2="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD"
@@ -20,8 +21,8 @@ run() {   # tag, bench args, rocprof args
   timeout -k 10 280 rocprofv3 "$@" --output-format csv -d $OUT/$tag -- python3 bench.py $args > $OUT/$tag.log 2>&1
   echo "$tag exit $?"
 }
-for w in ${PROFILE_WORKLOADS:-head c4 c5 c5t}; do
-  case $w in head) A=$HEAD_ARGS;; c5) A=$C5_ARGS;; c5t) A=$C5T_ARGS;; c4) A=$C4_ARGS;; esac
+for w in ${PROFILE_WORKLOADS:-head ref c4 c5 c5t}; do
+  case $w in head) A=$HEAD_ARGS;; c5) A=$C5_ARGS;; c5t) A=$C5T_ARGS;; c4) A=$C4_ARGS;; ref) A=$REF_ARGS;; esac
   if [ $w = head ]; then
     run ${w}_stats "$HEAD_STATS_ARGS" --kernel-trace --stats
     run ${w}1_stats "$HEAD_STATS_ARGS --frames-in-flight 1" --kernel-trace --stats
@@ -42,7 +43,7 @@ if [ -z "$PROFILE_WORKLOADS" ] || [[ "$PROFILE_WORKLOADS" == *post* ]]; then
   timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/post_stats -- python3 tools/post_profile.py 3840 2160 10 > $OUT/post_stats.log 2>&1; echo "post exit $?"
 fi
 python3 tools/pmc_to_json.py $OUT > $OUT/r4_counters.json && cp $OUT/r4_counters.json gpurun_out/r4_counters.json
-for t in head head1 c5 c5t c4 slab post; do f=$(find $OUT/${t}_stats -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp $f gpurun_out/r4_${t}_kernel_stats.csv; done
+for t in head head1 ref c5 c5t c4 slab post; do f=$(find $OUT/${t}_stats -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp $f gpurun_out/r4_${t}_kernel_stats.csv; done
 python3 - <<'PY'
 import json
 d = json.load(open("gpurun_out/r4_counters.json"))
