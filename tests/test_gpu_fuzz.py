@@ -40,6 +40,7 @@ def test_random_cases_match_oracle(scene_name, procedural_region, blue_noise):
         for kernel, flags in ((abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_COUNTERS),
                               (abi.RT_KERNEL_PERSISTENT, abi.RT_FLAG_CACHE_PRIMARY),
                               (abi.RT_KERNEL_PATHS, abi.RT_FLAG_CACHE_PRIMARY),
+                              (abi.RT_KERNEL_FRAME, abi.RT_FLAG_CACHE_PRIMARY),
                               (abi.RT_KERNEL_MEGA, abi.RT_FLAG_COUNTERS)):
             cfg = render.make_config(case["W"], case["H"], spp=case["spp"], depth=case["depth"], kernel=kernel, flags=flags)
             with render.Context(cfg) as ctx:

@@ -1,11 +1,12 @@
-# extended random cases for k_paths (not part of the suite): tools/fuzz_lr.py SEED N — scrolled windows (many lr, some far from the
+# extended random cases for k_paths (FUZZ_KERNEL=frame: k_frame) (not part of the suite): tools/fuzz_lr.py SEED N — scrolled windows (many lr, some far from the
 # origin where rays stall and meet the loop limit), lr = 0, poses near and beyond the window's faces; planes against the oracle, and
 # for every fifth case the exact cached-primary counters of the counting build
-import sys, numpy as np
+import os, sys, numpy as np
 sys.path.insert(0, ".")
 from raytrace_amd import abi, render, world
 from oracle import pyoracle as po
 from tests import scenes
+KERNEL = abi.RT_KERNEL_FRAME if os.environ.get('FUZZ_KERNEL') == 'frame' else abi.RT_KERNEL_PATHS
 noise = np.fromfile("tests/golden/blue_noise_512.rgba", dtype=np.uint8)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 bad = 0
@@ -34,16 +35,16 @@ for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     spp = int(rng.integers(1, 4)); depth = int(rng.integers(1, 7))
     u = po.camera_uniforms(tuple(float(x) for x in o), float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5)), int(rng.integers(0, abi.NOISE_BYTES)), lr)
     cpu, ccn = po.render(mats, mine, noise, u, W, H, spp, depth)
-    cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=abi.RT_KERNEL_PATHS, flags=abi.RT_FLAG_CACHE_PRIMARY)
+    cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=KERNEL, flags=abi.RT_FLAG_CACHE_PRIMARY)
     with render.Context(cfg) as ctx:
         ctx.upload_world(mats, mine); ctx.upload_noise(noise); ctx.draw_frame(u); ctx.sync()
-        assert ctx.kernel_in_use() == abi.RT_KERNEL_PATHS
+        assert ctx.kernel_in_use() == KERNEL
         gpu = ctx.readback_all()
     for name in cpu:
         if not np.array_equal(gpu[name], cpu[name], equal_nan=True):
             bad += 1; print("MISMATCH", i, name, lr, tuple(o), W, H, spp, depth, int(np.count_nonzero(gpu[name] != cpu[name]))); break
     if i % 5 == 0:   # the counting build: exact counters (the oracle's, minus the primaries the cache saves)
-        cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=abi.RT_KERNEL_PATHS, flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS)
+        cfg = render.make_config(W, H, spp=spp, depth=depth, kernel=KERNEL, flags=abi.RT_FLAG_CACHE_PRIMARY | abi.RT_FLAG_COUNTERS)
         with render.Context(cfg) as ctx:
             ctx.upload_world(mats, mine); ctx.upload_noise(noise); ctx.draw_frame(u); ctx.sync()
             gcn = ctx.counters().as_dict()
