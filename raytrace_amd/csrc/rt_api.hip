@@ -34,9 +34,10 @@ constexpr size_t kCursorWords = 8 * 32;   // path cursors of the persistent kern
 constexpr uint64_t kPathsCrossover = 3ull << 20;
 // ... and ONE-sample frames of fewer pixels than this run on k_frame — the whole frame in one launch, no prepass, worklist or
 // accumulate (rt_frame.hip; RT_FRAME_CROSSOVER overrides).  Measured (profiles/r4_frame_kernel.txt), k_frame against prepass +
-// k_persist, ms per frame: 256^2 0.098 / 0.186, 1024^2 (the reference's frame) 0.176 / 0.225, 1920x1080 0.293 / 0.296; with more
-// than one sample per pixel a lane walks them one after the other and the persistent kernels win (256^2 spp 4: 0.200 / 0.188).
-constexpr uint64_t kFrameCrossover = 3ull << 19;
+// k_persist, ms per frame: 256^2 0.084 / 0.186, 1024^2 (the reference's frame) 0.163 / 0.225, 1280x720 0.155 / 0.218, 1920x1080
+// 0.275 / 0.297, 2048x1440 0.355 / 0.360 (k_paths: 0.353); with more than one sample per pixel a lane walks them one after the
+// other and the persistent kernels win (256^2 spp 4: 0.200 / 0.188).
+constexpr uint64_t kFrameCrossover = 5ull << 19;
 // light records of one launch above which k_paths streams them out and k_accumulate_paths streams them in (see rt_draw_frame)
 constexpr uint64_t kStreamRecordBytes = 384ull << 20;
 

@@ -351,10 +351,11 @@ static void launch_frame_logr(const Scene& sc, const Frame& f, const Planes& pl,
 hipError_t launch_frame(const Scene& sc, const Frame& f, const Planes& pl, FrameArgs a, bool count, int num_cus, hipStream_t st) {
     if (f.ntiles_local <= 0) return hipSuccess;
     if (!launch_frame_ok(f)) return hipErrorInvalidValue;
-    // Tiles per wave: as many as it takes for ALL workgroups to be resident at once with about four waves per SIMD (a wave then
-    // refills its lanes from the workgroup's queue instead of leaving them idle while the tile's longest path finishes, and no
-    // workgroup starts late) — one for frames of up to 4 x 4 x CUs tiles (512 x 512 pixels on 256 CUs), at most kFrameMaxTilesPerWave.
-    const uint32_t ntiles = (uint32_t)f.ntiles_local, resident = 16u * (uint32_t)(num_cus > 0 ? num_cus : 256);
+    // Tiles per wave: as many as it takes for ALL workgroups to be resident at once — five waves per SIMD at this kernel's register
+    // count — so that no workgroup starts late; a wave then refills its lanes from the workgroup's queue instead of leaving them idle
+    // while a tile's longest path finishes.  One for frames of up to 20 x CUs tiles (512 x 512 pixels on 256 CUs), at most
+    // kFrameMaxTilesPerWave (measured, ms per frame with 2 / 3 / 4 tiles: 1280 x 720 0.182 / 0.144 / 0.155, 1920 x 1080 0.323 / 0.293 / 0.271).
+    const uint32_t ntiles = (uint32_t)f.ntiles_local, resident = 20u * (uint32_t)(num_cus > 0 ? num_cus : 256);
     uint32_t k = a.tiles_per_wave ? a.tiles_per_wave : (ntiles + resident - 1u) / resident;
     if (k < 1u) k = 1u;
     if (k > kFrameMaxTilesPerWave) k = kFrameMaxTilesPerWave;
@@ -362,7 +363,7 @@ hipError_t launch_frame(const Scene& sc, const Frame& f, const Planes& pl, Frame
     static const bool pair_a = getenv("RT_FRAME_PAIR_A") == nullptr || atoi(getenv("RT_FRAME_PAIR_A")) != 0;
     a.pair_a = pair_a ? 1u : 0u;
     const dim3 grid((ntiles + kFrameWgWaves * k - 1u) / (kFrameWgWaves * k));
-    if (a.threshold < 1u || a.threshold > 64u) a.threshold = 32u;
+    if (a.threshold < 1u || a.threshold > 64u) a.threshold = 44u;   // parked lanes per pass: 20 0.167 ms on the reference frame, 28 0.166, 40 0.162, 48 0.161, 56 0.166
     if (f.logr == 8) launch_frame_logr<8>(sc, f, pl, a, count, grid, st);
     else if (f.logr == 9) launch_frame_logr<9>(sc, f, pl, a, count, grid, st);
     else launch_frame_logr<10>(sc, f, pl, a, count, grid, st);

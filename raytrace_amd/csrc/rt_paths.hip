@@ -67,9 +67,6 @@
 #ifndef RT_PATHS_SHADOW_REPS
 #define RT_PATHS_SHADOW_REPS 0x3
 #endif
-#ifndef RT_PATHS_DRAIN_SKIP_NEW
-#define RT_PATHS_DRAIN_SKIP_NEW 0
-#endif
 #ifndef RT_PATHS_BRICK_MAP
 #define RT_PATHS_BRICK_MAP 0    // regions above 256: 1 = consult a global per-brick nibble map (Scene::brick; RT_BRICK_MAP=1 makes the host build it) before
                                 // the byte array.  Measured and NOT kept: it answers 11 % of the loop's fetches at R = 1024 and costs every step on a
@@ -303,21 +300,6 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         // (depth <= 4 builds only — the reference's frames are depth 2; launch_paths_direct_ok tells the host)
         uint32_t lp_done = 0;
         if (STK == 0 && a.direct) lp_done = a.worklist[fin ? Pitem : 0u];
-#if RT_PATHS_DRAIN_SKIP_NEW   // experiment (round 4): a wave whose paths have run out starts no new ones — skip their loads and the round trip of the second noise lookup
-        float4 ph = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint32_t nse = 0u;
-        if (!exhausted) {
-            ph = a.phit[nw];
-            const uint32_t seed = (f.seed + a.sample0 + nsb) % (uint32_t)RT_NOISE_BYTES;
-            const uint32_t by = seed / RT_NOISE_SIZE;
-            const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
-            const uint32_t i0 = u_bits(ph.w);
-            const uint32_t ntx = ((nb & 0xFFu) + (i0 & 0x3FFFu)) & 511u, nty = (((nb >> 8) & 0xFFu) + ((i0 >> 14) & 0x3FFFu)) & 511u;
-            nse = sc.noise[nty * RT_NOISE_SIZE + ntx] & 0xFFFFu;
-        }
-        const uint32_t info = u_bits(ph.w);
-        const float ox = ph.x, oy = ph.y, oz = ph.z;
-#else
         const float4 ph = a.phit[nw];       // the prepass' record of the new path's pixel: one 16-byte load
         const uint32_t info = u_bits(ph.w);
         const float ox = ph.x, oy = ph.y, oz = ph.z;
@@ -329,7 +311,6 @@ __global__ __launch_bounds__(1024) void k_paths(Scene sc, Frame f, Planes pl, Pe
         const uint32_t wgx8 = info & 0x3FFFu, wgy8 = (info >> 14) & 0x3FFFu;
         const uint32_t ntx = ((nb & 0xFFu) + wgx8) & 511u, nty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
         const uint32_t nse = sc.noise[nty * RT_NOISE_SIZE + ntx] & 0xFFFFu;   // second round trip, new paths only
-#endif
         // depth 5..8 at region 256: the stack levels that live in global memory (4..7) ride in the first batch — the sum below
         // then makes no round trips of its own
         uint32_t pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;

@@ -123,7 +123,7 @@ def test_frame_kernel_far_window_reaches_the_loop_limit(native_built, blue_noise
 
 
 def test_the_reference_frame_runs_on_the_frame_kernel_by_default(procedural_region, blue_noise):
-    """RT_KERNEL_DEFAULT: one-sample frames of fewer than 1.5 M pixels — the reference's 1024 x 1024 — run on k_frame, larger
+    """RT_KERNEL_DEFAULT: one-sample frames of fewer than 2.5 M pixels — the reference's 1024 x 1024 — run on k_frame, larger
     one-sample frames and every multi-sample frame on the persistent kernels.  The whole 1024 x 1024 frame against the oracle
     (two frames drawn: the second must not depend on anything the first left behind), counters included."""
     mats, mine = procedural_region
@@ -133,7 +133,8 @@ def test_the_reference_frame_runs_on_the_frame_kernel_by_default(procedural_regi
     gpu, gcn = _render_frame_kernel(mats, mine, blue_noise, u, W, H, 1, 2, frames=2, kernel=abi.RT_KERNEL_DEFAULT)
     _compare(gpu, cpu)
     assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, 1, 2, ccn)
-    for (w, h, spp, want) in ((1920, 1080, 1, abi.RT_KERNEL_PERSISTENT), (256, 256, 2, abi.RT_KERNEL_PERSISTENT), (256, 256, 1, abi.RT_KERNEL_FRAME)):
+    for (w, h, spp, want) in ((2304, 1152, 1, abi.RT_KERNEL_PERSISTENT), (256, 256, 2, abi.RT_KERNEL_PERSISTENT), (256, 256, 1, abi.RT_KERNEL_FRAME),
+                               (1920, 1080, 1, abi.RT_KERNEL_FRAME)):
         with render.Context(render.make_config(w, h, spp=spp, depth=2, flags=CACHE)) as ctx:
             ctx.upload_world(mats, mine)
             ctx.upload_noise(blue_noise)

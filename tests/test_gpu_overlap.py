@@ -191,7 +191,7 @@ def test_one_sample_frames_store_their_lighting_in_the_path_kernel(procedural_re
 
 def test_default_kernel_switches_to_k_paths_for_one_sample_frames_of_three_million_pixels(procedural_region, blue_noise):
     """RT_KERNEL_DEFAULT runs launches of >= 3 M pixel-samples on k_paths: a 2304 x 1408 one-sample frame (3.24 M pixels) is on
-    k_paths' direct path, a 1920 x 1080 one on k_persist's (below 1.5 M pixels k_frame takes over: tests/test_gpu_frame_kernel.py); two
+    k_paths' direct path, a 2304 x 1152 one on k_persist's (below 2.5 M pixels k_frame takes over: tests/test_gpu_frame_kernel.py); two
     8-row bands of the big frame against the oracle."""
     mats, mine = procedural_region
     W, H, depth = 2304, 1408, 2
@@ -209,7 +209,7 @@ def test_default_kernel_switches_to_k_paths_for_one_sample_frames_of_three_milli
         band, _ = po.render(mats, mine, blue_noise, u, W, H, 1, depth, rows=(y0, y0 + 8))
         for name in band:
             assert np.array_equal(got[name][y0:y0 + 8], band[name][y0:y0 + 8], equal_nan=True), (name, y0)
-    with render.Context(render.make_config(1920, 1080, spp=1, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY)) as ctx:
+    with render.Context(render.make_config(2304, 1152, spp=1, depth=depth, flags=abi.RT_FLAG_CACHE_PRIMARY)) as ctx:
         ctx.upload_world(mats, mine)
         ctx.upload_noise(blue_noise)
         ctx.draw_frame(u)
