@@ -9,7 +9,7 @@ unrolled RT_PATHS_STEPS_PER_CHECK repetitions of the four ray slots).  The scrip
 """
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-files = ["rt_paths.hip", "rt_persist.hip", "rt_kernels.hip", "rt_post.hip"]
+files = ["rt_paths.hip", "rt_frame.hip", "rt_persist.hip", "rt_kernels.hip", "rt_post.hip"]
 FLAGS = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"),
          "--cuda-device-only"]
 
