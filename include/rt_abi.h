@@ -91,7 +91,7 @@ typedef struct RtUniforms {
 
 /* Which traversal implementation a context uses. */
 typedef enum RtKernel {
-    RT_KERNEL_DEFAULT = 0,    /* library picks: paths / persistent by work size                                                  */
+    RT_KERNEL_DEFAULT = 0,    /* library picks per frame: frame (one-sample frames < 2.5 M pixels) / paths / persistent by work size */
     RT_KERNEL_MEGA = 1,       /* one thread per pixel, all rays inline, byte minefield from HBM (baseline)      */
     RT_KERNEL_WAVEFRONT = 2,  /* split stages: persistent traversal kernel fed by SoA ray/hit queues in HBM     */
     RT_KERNEL_PERSISTENT = 3, /* production kernel: persistent wave64 path kernel, a lane owns a path with its shadow

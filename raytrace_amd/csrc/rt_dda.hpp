@@ -50,7 +50,7 @@ __device__ __forceinline__ void dda_fill_swz(uint32_t* s_swz, uint32_t tid, uint
         s_swz[a * kSwzStride + i % 257u] = ((v & 3u) << (2u * a)) | ((v >> 2) << (6u + 6u * a));
     }
 }
-template <int LOGR, bool LRZ, bool COUNT, bool GENERIC_Q>
+template <int LOGR, bool LRZ, bool COUNT, bool GENERIC_Q, bool SWZ = dda_uses_swz<LOGR, LRZ>()>
 __device__ __forceinline__ void dda_advance(RaySlot2& r, uint32_t step, const Frame& f, float half, unsigned long long& c_border,
                                             const uint32_t* s_swz) {
     constexpr int R = 1 << LOGR, LB = LOGR - 2;
@@ -91,7 +91,7 @@ __device__ __forceinline__ void dda_advance(RaySlot2& r, uint32_t step, const Fr
                              : (rtm_abs(r.px - f.lr[0]) >= half || rtm_abs(r.py - f.lr[1]) >= half || rtm_abs(r.pz - f.lr[2]) >= half);
         if (sky) {
             r.nk |= PX_AIR << 16; r.tracing = false;
-        } else if (dda_uses_swz<LOGR, LRZ>()) {
+        } else if (SWZ) {
             r.vox = s_swz[(int)r.ux] | s_swz[kSwzStride + (int)r.uy] | s_swz[2 * kSwzStride + (int)r.uz];   // u in [0, 256]
         } else if (LRZ) {
             const int ix = (int)r.ux & (R - 1), iy = (int)r.uy & (R - 1), iz = (int)r.uz & (R - 1);
@@ -110,7 +110,7 @@ __device__ __forceinline__ void dda_advance(RaySlot2& r, uint32_t step, const Fr
 // Head of trace_ray (:83-107) for a ray with direction d (already normalized, :83) from origin ro whose first texel is
 // (vox0, cidx0), ok = that texel is inside the texture.  r.l* (1/|d|, :88) must be set by the caller.  DIRECT (k_frame): there
 // is no nibble map in LDS (s_nib unused), the value is the byte of the array.
-template <int LOGR, bool LRZ, bool COUNT, bool DIRECT = false>
+template <int LOGR, bool LRZ, bool COUNT, bool DIRECT = false, bool SWZ = dda_uses_swz<LOGR, LRZ>()>
 __device__ __forceinline__ void dda_arm(RaySlot2& r, float dx, float dy, float dz, float rox, float roy, float roz, bool ok,
                                         uint32_t vox0, uint32_t cidx0, const Frame& f, float half, const uint8_t* s_nib,
                                         const Scene& sc, unsigned long long& c_border, const uint32_t* s_swz) {
@@ -122,7 +122,7 @@ __device__ __forceinline__ void dda_arm(RaySlot2& r, float dx, float dy, float d
     // NaN direction, or a first texel outside the texture (border value 0: step_size 0 on a fresh ray): the ray ends at once
     if (dx != dx || dy != dy || dz != dz || !ok) { r.nk = 1u | PX_SPECIAL << 16; r.tracing = false; }
     if (LRZ && __builtin_expect(r.tracing && (r.ux < 0.0f || r.uy < 0.0f || r.uz < 0.0f), 0))   // rare (origin outside the region): see dda_advance
-        dda_advance<LOGR, LRZ, COUNT, true>(r, DIRECT ? (uint32_t)sc.mine[r.vox] : dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border, s_swz);
+        dda_advance<LOGR, LRZ, COUNT, true, SWZ>(r, DIRECT ? (uint32_t)sc.mine[r.vox] : dda_lookup<LOGR>(r, s_nib, sc), f, half, c_border, s_swz);
 }
 
 // Exact counters of one finished ray (the counting build's share of SURVEY 8d's integers).

@@ -41,19 +41,23 @@ constexpr uint32_t kFrameMaxTilesPerWave = 4;   // sizes the workgroup's pixel q
 #define RT_FRAME_WG_WAVES 4      // waves per workgroup: they share the pixel queue
 #endif
 constexpr uint32_t kFrameWgWaves = RT_FRAME_WG_WAVES, kFrameWg = 64u * kFrameWgWaves;
+#ifndef RT_FRAME_SWZ
+#define RT_FRAME_SWZ 1           // 1: the swizzled index of a ray's next texel from three LDS table reads (region 256, lr = 0); 0: from shifts and masks
+#endif
 #ifndef RT_FRAME_WAVES_PER_SIMD
 #define RT_FRAME_WAVES_PER_SIMD 5
 #endif
 template <int LOGR, bool LRZ, bool COUNT>
 __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Scene sc, Frame f, Planes pl, FrameArgs a) {
     __shared__ float s_albedo[128];            // (packed >> k & 0x7F) / 127.0 (raytrace.comp:156-158), exact quotients
-    __shared__ uint32_t s_swz[dda_uses_swz<LOGR, LRZ>() ? 3 * kSwzStride : 1];   // swizzle tables (rt_dda.hpp)
+    constexpr bool SWZ = RT_FRAME_SWZ != 0 && dda_uses_swz<LOGR, LRZ>();
+    __shared__ uint32_t s_swz[SWZ ? 3 * kSwzStride : 1];   // swizzle tables (rt_dda.hpp)
     __shared__ uint32_t s_stack[kFrameLdsStack][kFrameWg];   // packed material of surface j+1 at level j, per lane
     __shared__ float4 s_queue[kFrameMaxTilesPerWave * kFrameWg];   // the workgroup's non-sky pixels: primary hit, and face id << 28 | local pixel
     __shared__ uint32_t s_qtail, s_qhead;
     if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
     if (threadIdx.x == 0u) { s_qtail = 0u; s_qhead = 0u; }
-    if (dda_uses_swz<LOGR, LRZ>()) dda_fill_swz(s_swz, threadIdx.x, kFrameWg);
+    if (SWZ) dda_fill_swz(s_swz, threadIdx.x, kFrameWg);
     __syncthreads();
 
     constexpr int R = 1 << LOGR, LB = LOGR - 2;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
     const unsigned long long t_start = kTimes ? wall_clock64() : 0ull;
     unsigned long long t_mid = 0;
     RayTally tl;
-    auto advance = [&](RaySlot2& r, uint32_t step) { dda_advance<LOGR, LRZ, COUNT, false>(r, step, f, half, c_border, s_swz); };
+    auto advance = [&](RaySlot2& r, uint32_t step) { dda_advance<LOGR, LRZ, COUNT, false, SWZ>(r, step, f, half, c_border, s_swz); };
 
     RaySlot2 S, F;
     S.px = S.py = S.pz = S.ndx = S.ndy = S.lx = S.ly = S.lz = S.ux = S.uy = S.uz = 0.0f; S.ndz = -1.0f;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
             r.lx = 1.0f / rtm_abs(d.x); r.ly = 1.0f / rtm_abs(d.y); r.lz = 1.0f / rtm_abs(d.z);       // :88
             int ix, iy, iz;
             const bool ok = wrap_texel(start, (float)R, &ix, &iy, &iz);
-            dda_arm<LOGR, LRZ, COUNT, true>(r, d.x, d.y, d.z, start.x, start.y, start.z, ok, swizzled_index(ix, iy, iz, LB), 0u, f, half,
+            dda_arm<LOGR, LRZ, COUNT, true, SWZ>(r, d.x, d.y, d.z, start.x, start.y, start.z, ok, swizzled_index(ix, iy, iz, LB), 0u, f, half,
                                             nullptr, sc, c_border, s_swz);
         }
     };
@@ -307,8 +311,8 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
                     F.ndx = -d2.x; F.ndy = -d2.y; F.ndz = -d2.z; F.lx = dl.x; F.ly = dl.y; F.lz = dl.z;
                     dif_entry = di;
                 }
-                dda_arm<LOGR, LRZ, COUNT, true>(S, -S.ndx, -S.ndy, -S.ndz, sfx, sfy, sfz, ok, vox0, 0u, f, half, nullptr, sc, c_border, s_swz);
-                dda_arm<LOGR, LRZ, COUNT, true>(F, -F.ndx, -F.ndy, -F.ndz, sfx, sfy, sfz, ok, vox0, 0u, f, half, nullptr, sc, c_border, s_swz);
+                dda_arm<LOGR, LRZ, COUNT, true, SWZ>(S, -S.ndx, -S.ndy, -S.ndz, sfx, sfy, sfz, ok, vox0, 0u, f, half, nullptr, sc, c_border, s_swz);
+                dda_arm<LOGR, LRZ, COUNT, true, SWZ>(F, -F.ndx, -F.ndy, -F.ndz, sfx, sfy, sfz, ok, vox0, 0u, f, half, nullptr, sc, c_border, s_swz);
             }
         }
     }

@@ -35,10 +35,12 @@ def test_abi_minor_version_is_pinned_and_its_history_is_in_the_header():
     text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
     major = int(re.search(r"#define RT_ABI_VERSION_MAJOR (\d+)", text).group(1))
     minor = int(re.search(r"#define RT_ABI_VERSION_MINOR (\d+)", text).group(1))
-    assert (major, minor) == (1, 2)
+    assert (major, minor) == (1, 3)
     assert lib.rt_abi_version() == (major << 16) | minor
-    for needle in ("1.1  round 3: rt_slice_staging", "1.2  round 4: RT_FLAG_FRAMES_IN_FLIGHT_2", "rt_samples_per_launch", "rt_get_gather_timing"):
+    for needle in ("1.1  round 3: rt_slice_staging", "1.2  round 4: RT_FLAG_FRAMES_IN_FLIGHT_2", "rt_samples_per_launch", "rt_get_gather_timing",
+                   "1.3  round 4: RtKernel value 7 (RT_KERNEL_FRAME)"):
         assert needle in text, needle
+    assert abi.RT_KERNEL_FRAME == int(re.search(r"RT_KERNEL_FRAME = (\d+),", text).group(1)) == 7
     assert abi.RT_FLAG_FRAMES_IN_FLIGHT_2 == int(re.search(r"#define RT_FLAG_FRAMES_IN_FLIGHT_2 (0x[0-9a-f]+)u", text).group(1), 16)
     assert C.sizeof(abi.RtInfo) == 40 and abi.RtInfo.launches_in_flight.offset == 12 and abi.RtInfo.frames_in_flight.offset == 14
 
