@@ -779,7 +779,10 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         // This frame's slot, and the lane its prepass and first path launch go to (launches alternate between the lanes).
         const int si = nsl == 2 ? (int)(ctx->frames_drawn & 1u) : 0;
         FrameSlot& fs = ctx->slots[si];
-        Lane* L0 = &ctx->lanes[ctx->path_launches % (uint64_t)nl];
+        // (a one-slot context whose frames are one launch each stays on lane 0: frame k + 1 cannot start before frame k has finished
+        // with the slot, so alternating would only put an event wait between two streams in front of every frame)
+        const bool one_lane = nsl == 1 && (uint32_t)ctx->cfg.spp <= ctx->persist_batch;
+        Lane* L0 = &ctx->lanes[one_lane ? 0u : ctx->path_launches % (uint64_t)nl];
         const hipStream_t st0 = L0->stream;
         // the frame that used the slot before (frame k - 2 with two slots, k - 1 with one) has finished with it
         if (e == hipSuccess && fs.tail_recorded) e = hipStreamWaitEvent(st0, fs.ev_tail, 0);
@@ -845,9 +848,9 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
             for (uint32_t s0 = 0; s0 < spp && e == hipSuccess; s0 += B) {
                 const uint32_t ns = spp - s0 < B ? spp - s0 : B;
                 // the sample batches of a frame alternate between the lanes: batch b + 1 starts on the CUs batch b's workgroups leave
-                Lane* L = &ctx->lanes[ctx->path_launches % (uint64_t)nl];
+                Lane* L = &ctx->lanes[one_lane ? 0u : ctx->path_launches % (uint64_t)nl];
                 const hipStream_t st = L->stream;
-                ctx->path_launches++;
+                if (!one_lane) ctx->path_launches++;
                 if (st != st0 && s0 == B) e = hipStreamWaitEvent(st, fs.ev_prepass, 0);   // (later batches on that lane follow by stream order)
                 if (e == hipSuccess && !L->cursor_clean) e = hipMemsetAsync(L->cursor, 0, kCursorWords * sizeof(uint32_t), st);
                 L->cursor_clean = false;
