@@ -105,7 +105,7 @@ typedef enum RtKernel {
     RT_KERNEL_FRAME = 7,      /* (ABI 1.3) the whole frame in ONE launch: a wave per 8x8 tile walks the tile's primary rays and then
                                  every sample's path of each of its pixels (sums in registers; no prepass, worklist, light records or
                                  accumulate launch).  What RT_KERNEL_DEFAULT runs for frames with little work (the reference's own
-                                 1024 x 1024, 1 sample, depth 2).  Needs RT_FLAG_CACHE_PRIMARY and depth <= 8; other frames of such a
+                                 1024 x 1024, 1 sample, depth 2).  Needs RT_FLAG_CACHE_PRIMARY (or one sample per pixel) and depth <= 8; other frames of such a
                                  context run on RT_KERNEL_PATHS / RT_KERNEL_PERSISTENT                                          */
 } RtKernel;
 

@@ -793,7 +793,8 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         uint32_t* const wln = fs.wl_count + 32 * (fs.wl_parity ^ 1);
         const bool prepass_clears = cache && ctx->primary_version == 2 && ctx->npix_pad != 0;
         // k_frame: the whole frame in one launch (cached primaries by construction; frames it does not cover go the persistent way)
-        const bool one_launch = cache && rtd::launch_frame_ok(f) &&
+        // (with one sample per pixel "cached primaries" is what every kernel does anyway: the flag is not needed)
+        const bool one_launch = (cache || ctx->cfg.spp == 1) && rtd::launch_frame_ok(f) &&
                                 (ctx->frame_mode == 2 || (ctx->frame_mode == 1 && ctx->cfg.spp == 1 && (uint64_t)ctx->npix_pad < ctx->frame_crossover));
         if (e == hipSuccess && cache && !one_launch) {
             if (!fs.wl_clean[fs.wl_parity]) e = hipMemsetAsync(wlc, 0, sizeof(uint32_t), st0);
@@ -1277,7 +1278,7 @@ int rt_get_info(RtContext* ctx, RtInfo* out) {
 int rt_kernel_in_use(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->last_path_kernel != 0) return ctx->last_path_kernel;   // what the last frame ran
-    if (ctx->kernel == RT_KERNEL_PERSISTENT && (ctx->cfg.flags & RT_FLAG_CACHE_PRIMARY) && ctx->cfg.depth <= 8 &&
+    if (ctx->kernel == RT_KERNEL_PERSISTENT && ((ctx->cfg.flags & RT_FLAG_CACHE_PRIMARY) || ctx->cfg.spp == 1) && ctx->cfg.depth <= 8 &&
         (ctx->frame_mode == 2 || (ctx->frame_mode == 1 && ctx->cfg.spp == 1 && (uint64_t)ctx->npix_pad < ctx->frame_crossover)))
         return RT_KERNEL_FRAME;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 3) return RT_KERNEL_PATHS;

@@ -145,6 +145,26 @@ def test_the_reference_frame_runs_on_the_frame_kernel_by_default(procedural_regi
             assert ctx.kernel_in_use() == want
 
 
+def test_one_sample_frames_need_no_cache_flag(procedural_region, blue_noise):
+    """With one sample per pixel every kernel traces the primary ray once, so RT_KERNEL_DEFAULT runs such a frame on k_frame whether
+    or not the host set RT_FLAG_CACHE_PRIMARY (the C++ mirror and a host bound against ABI 1.0 do not): planes and the oracle's own
+    (un-cached) counters."""
+    mats, mine = procedural_region
+    u = _uniforms(seed=6)
+    W, H = 136, 72
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, 1, 2)
+    cfg = render.make_config(W, H, spp=1, depth=2, flags=abi.RT_FLAG_COUNTERS)
+    with render.Context(cfg) as ctx:
+        ctx.upload_world(mats, mine)
+        ctx.upload_noise(blue_noise)
+        assert ctx.kernel_in_use() == abi.RT_KERNEL_FRAME
+        ctx.draw_frame(u)
+        ctx.sync()
+        assert ctx.kernel_in_use() == abi.RT_KERNEL_FRAME
+        gpu, gcn = ctx.readback_all(), ctx.counters()
+    _compare(gpu, cpu, gcn, ccn)
+
+
 def test_frames_the_frame_kernel_does_not_cover_run_on_the_persistent_kernels(procedural_region, blue_noise):
     """RT_KERNEL_FRAME asked for a frame outside k_frame's range (depth 9: eight albedo-stack levels; or no primary cache): the
     context falls back to k_paths / k_persist, says so, and the frame is still the oracle's."""
