@@ -38,6 +38,12 @@ constexpr uint64_t kPathsCrossover = 3ull << 20;
 // 0.275 / 0.297, 2048x1440 0.355 / 0.360 (k_paths: 0.353); with more than one sample per pixel a lane walks them one after the
 // other and the persistent kernels win (256^2 spp 4: 0.200 / 0.188).
 constexpr uint64_t kFrameCrossover = 5ull << 19;
+// More than one sample per pixel: k_frame deals the (pixel, sample) paths of a workgroup's pixels to its lanes and adds a pixel's
+// samples in order itself.  It wins while the frame is so small that the persistent kernels' ~0.14 ms per launch dominates — measured
+// (k_frame / k_persist, ms per frame): 256^2 spp 2 depth 2 0.105 / 0.176, spp 4 depth 2 0.106 / 0.179, 128^2 spp 16 depth 4 0.213 / 0.206,
+// 256^2 spp 16 depth 4 0.246 / 0.211, 512^2 spp 4 depth 4 0.234 / 0.217, 1024^2 spp 2 depth 4 0.352 / 0.290 — i.e. below about 1.5 M
+// pixel-sample-levels (pixels x spp x depth; RT_FRAME_CROSSOVER_MULTI overrides).
+constexpr uint64_t kFrameCrossoverMulti = 3ull << 19;
 // light records of one launch above which k_paths streams them out and k_accumulate_paths streams them in (see rt_draw_frame)
 constexpr uint64_t kStreamRecordBytes = 384ull << 20;
 
@@ -139,8 +145,9 @@ struct RtContext {
     bool paths_by_size = false;   // RT_KERNEL_DEFAULT: k_paths for launches with enough work, k_persist for small ones
     int frame_mode = 0;           // k_frame: 0 = never, 1 = one-sample frames below frame_crossover pixels (RT_KERNEL_DEFAULT), 2 = every frame it covers (RT_KERNEL_FRAME)
     uint64_t frame_crossover = kFrameCrossover;
+    uint64_t frame_crossover_multi = kFrameCrossoverMulti;   // ... and frames of more than one sample per pixel below this many pixel-sample-levels
     uint32_t frame_threshold = 0; // RT_FRAME_THRESHOLD: parked lanes per wave that trigger k_frame's pass; 0 = the default
-    uint32_t frame_tiles = 0;     // RT_FRAME_TILES: tiles per wave of k_frame (1..4); 0 = by frame size
+    uint32_t frame_tiles = 0;     // RT_FRAME_TILES (per wave, 1..4) / RT_FRAME_GROUP_TILES (1..16): tiles per four-wave workgroup of k_frame; 0 = by frame size and spp
     int last_path_kernel = 0;     // RtKernel the most recent frame's path launches ran on (0 = no frame yet)
     float lut_key[6] = {0, 0, 0, 0, 0, 0};   // sun vector + colour the per-frame tables were built for
     bool lut_valid = false;
@@ -199,6 +206,12 @@ hipError_t dev_alloc(RtContext* c, T** p, size_t count) {
     hipError_t e = hipMalloc((void**)p, count * sizeof(T));
     if (e == hipSuccess) { c->allocs.push_back((void*)*p); c->device_bytes += count * sizeof(T); }
     return e;
+}
+
+// RT_KERNEL_DEFAULT: is this context's frame small enough for k_frame (one launch per frame)?
+bool frame_by_size(const RtContext* c) {
+    if (c->cfg.spp == 1) return (uint64_t)c->npix_pad < c->frame_crossover;
+    return (uint64_t)c->npix_pad * (uint64_t)c->cfg.spp * (uint64_t)(c->cfg.depth > 1 ? c->cfg.depth : 1) < c->frame_crossover_multi;
 }
 
 rtd::Scene scene_of(const RtContext* c) {
@@ -437,8 +450,10 @@ int rt_create(const RtConfig* cfg, RtContext** out) {
         // rest of those contexts' frames go the persistent way, so they hold its buffers as well
         c->frame_mode = cfg->kernel == RT_KERNEL_FRAME ? 2 : (cfg->kernel == RT_KERNEL_DEFAULT ? 1 : 0);
         if (const char* s = getenv("RT_FRAME_CROSSOVER")) { long long v = atoll(s); if (v >= 0) c->frame_crossover = (uint64_t)v; }
+        if (const char* s = getenv("RT_FRAME_CROSSOVER_MULTI")) { long long v = atoll(s); if (v >= 0) c->frame_crossover_multi = (uint64_t)v; }
         if (const char* s = getenv("RT_FRAME_THRESHOLD")) { int v = atoi(s); if (v >= 1 && v <= 64) c->frame_threshold = (uint32_t)v; }
-        if (const char* s = getenv("RT_FRAME_TILES")) { int v = atoi(s); if (v >= 1 && v <= 4) c->frame_tiles = (uint32_t)v; }
+        if (const char* s = getenv("RT_FRAME_TILES")) { int v = atoi(s); if (v >= 1 && v <= 4) c->frame_tiles = 4u * (uint32_t)v; }           // per wave
+        if (const char* s = getenv("RT_FRAME_GROUP_TILES")) { int v = atoi(s); if (v >= 1 && v <= 16) c->frame_tiles = (uint32_t)v; }     // per four-wave workgroup
         c->kernel = (cfg->kernel == RT_KERNEL_DEFAULT || cfg->kernel == RT_KERNEL_FRAME) ? RT_KERNEL_PATHS : cfg->kernel;
         if (c->kernel == RT_KERNEL_PATHS) { c->kernel = RT_KERNEL_PERSISTENT; c->persist_version = 3; }
     }
@@ -794,8 +809,9 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
         const bool prepass_clears = cache && ctx->primary_version == 2 && ctx->npix_pad != 0;
         // k_frame: the whole frame in one launch (cached primaries by construction; frames it does not cover go the persistent way)
         // (with one sample per pixel "cached primaries" is what every kernel does anyway: the flag is not needed)
-        const bool one_launch = (cache || ctx->cfg.spp == 1) && rtd::launch_frame_ok(f) &&
-                                (ctx->frame_mode == 2 || (ctx->frame_mode == 1 && ctx->cfg.spp == 1 && (uint64_t)ctx->npix_pad < ctx->frame_crossover));
+        // (more than one sample: the paths' light records go to the lane's array, which must hold the whole frame's)
+        const bool one_launch = (cache || ctx->cfg.spp == 1) && rtd::launch_frame_ok(f) && (ctx->cfg.spp == 1 || (uint32_t)ctx->cfg.spp <= ctx->persist_batch) &&
+                                (ctx->frame_mode == 2 || (ctx->frame_mode == 1 && frame_by_size(ctx)));
         if (e == hipSuccess && cache && !one_launch) {
             if (!fs.wl_clean[fs.wl_parity]) e = hipMemsetAsync(wlc, 0, sizeof(uint32_t), st0);
             fs.wl_clean[fs.wl_parity] = false;
@@ -832,7 +848,7 @@ int rt_draw_frame(RtContext* ctx, const RtUniforms* u) {
             // cross-stream event wait between them
             if (nsl == 2) ctx->path_launches++;
             rtd::FrameArgs fa{};
-            fa.threshold = ctx->frame_threshold; fa.tiles_per_wave = ctx->frame_tiles; fa.sun_lut = ctx->sun_lut; fa.dif_lut = ctx->dif_lut; fa.counters = ctx->d_counters;
+            fa.threshold = ctx->frame_threshold; fa.tiles_per_group = ctx->frame_tiles; fa.sun_lut = ctx->sun_lut; fa.dif_lut = ctx->dif_lut; fa.pl = L0->ppl; fa.counters = ctx->d_counters;
             if (getenv("RT_DEBUG_WAVE_DUMP") && (size_t)ctx->ntiles_local * 32u <= (size_t)4 * ctx->num_cus * 1024 * sizeof(uint32_t))
                 fa.dbg_waves = reinterpret_cast<unsigned long long*>(ctx->lanes[0].pstack);   // (idle while k_frame runs)
             LaunchTimer t(ctx, 0, st0);
@@ -1279,7 +1295,7 @@ int rt_kernel_in_use(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARG;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->last_path_kernel != 0) return ctx->last_path_kernel;   // what the last frame ran
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ((ctx->cfg.flags & RT_FLAG_CACHE_PRIMARY) || ctx->cfg.spp == 1) && ctx->cfg.depth <= 8 &&
-        (ctx->frame_mode == 2 || (ctx->frame_mode == 1 && ctx->cfg.spp == 1 && (uint64_t)ctx->npix_pad < ctx->frame_crossover)))
+        (ctx->cfg.spp == 1 || (uint32_t)ctx->cfg.spp <= ctx->persist_batch) && (ctx->frame_mode == 2 || (ctx->frame_mode == 1 && frame_by_size(ctx))))
         return RT_KERNEL_FRAME;
     if (ctx->kernel == RT_KERNEL_PERSISTENT && ctx->persist_version == 3) return RT_KERNEL_PATHS;
     return ctx->kernel;

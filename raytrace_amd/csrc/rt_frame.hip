@@ -146,11 +146,14 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
             }
         }
     };
-    const uint32_t jstep = a.pair_a ? 2u : 1u;
-    for (uint32_t j = 0; j < a.tiles_per_wave; j += jstep) {
-        const uint32_t tile0 = (j * kFrameWgWaves + wiw) * gridDim.x + blockIdx.x, tile1 = ((j + 1u) * kFrameWgWaves + wiw) * gridDim.x + blockIdx.x;
-        if (tile0 >= (uint32_t)f.ntiles_local) break;   // wave-uniform (the tile index grows with j)
-        const bool two = a.pair_a && j + 1u < a.tiles_per_wave && tile1 < (uint32_t)f.ntiles_local;
+    // the workgroup's tiles_per_group tiles are dealt to its waves in turn (wave w: tiles w, w + 4, ...); with many samples per pixel a
+    // group has fewer tiles than waves — the other waves go straight to the barrier and share the paths
+    const uint32_t istep = (a.pair_a ? 2u : 1u) * kFrameWgWaves;
+    for (uint32_t i0 = wiw; i0 < a.tiles_per_group; i0 += istep) {
+        const uint32_t i1 = i0 + kFrameWgWaves;
+        const uint32_t tile0 = i0 * gridDim.x + blockIdx.x, tile1 = i1 * gridDim.x + blockIdx.x;
+        if (tile0 >= (uint32_t)f.ntiles_local) break;   // wave-uniform (the tile index grows with i0)
+        const bool two = a.pair_a && i1 < a.tiles_per_group && tile1 < (uint32_t)f.ntiles_local;
         const uint32_t lp0 = tile0 * 64u + lane, lp1 = tile1 * 64u + lane;
         const PixelId pix0 = pixel_of_local(f, lp0);
         PixelId pix1 = pix0;
@@ -175,17 +178,20 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
     const uint32_t qtotal = s_qtail;
 
     // ---- phase B: the paths of the workgroup's non-sky pixels ----------------------------------------------------------------
-    // A lane takes a pixel from the queue, walks all its samples (sum in registers, sample order), stores the pixel's lighting and
-    // takes the next pixel; lanes are refilled in the transition pass, ballot-ranked, one LDS atomic per wave and pass.
+    // Work item w = s * qtotal + e: sample s of queue entry e (sample-major: a wave's lanes hold neighbouring pixels of one sample).
+    // A lane takes an item, walks that path — a level's shadow and diffuse ray together in two slots — and takes the next; lanes are
+    // refilled in the transition pass, ballot-ranked, one LDS atomic per wave and pass.  One sample per pixel (the reference's
+    // frames): the lane stores the pixel's lighting itself (0 + light: k_accumulate_paths' arithmetic).  More: the path's light goes
+    // to the light-record array (pl[pixel * spp + s]) and the workgroup adds a pixel's samples IN SAMPLE ORDER when all its paths
+    // have ended (below) — the deterministic fp32 sum the oracle defines, without a launch of its own.
     if (qtotal != 0u) {
         const uint32_t threshold = a.threshold;
         const uint32_t spp = (uint32_t)f.spp;
-        bool active = false, dry = false;   // active: the lane holds a pixel; dry (wave-uniform): the queue has been handed out
-        float p0x = 0, p0y = 0, p0z = 0;    // the pixel's primary hit: the surface every sample starts from
-        uint32_t n0lp = 0;                  // its face id << 28 | local pixel
-        uint32_t level = 0, sunbits = 0, samp = 0, nvtex = 0;   // level 0: the lane's next sample has not begun
+        const uint32_t nitems = qtotal * spp;   // <= 1024 * spp (the host keeps pixel-samples per frame far below 2^31)
+        bool active = false, dry = false;   // active: the lane holds a path; dry (wave-uniform): every item has been handed out
+        uint32_t n0lp = 0;                  // the path's pixel: face id of its primary hit << 28 | local pixel
+        uint32_t level = 0, sunbits = 0, samp = 0, nvtex = 0;
         uint32_t dif_entry = 0xFFFFFFFFu, sun_entry = 0xFFFFFFFFu;   // table entries held by F's / S's direction registers
-        float sumx = 0.0f, sumy = 0.0f, sumz = 0.0f;
         for (;;) {
             const uint64_t m_busy = __ballot(S.tracing || F.tracing);
             const uint64_t m_wait = __ballot(!(S.tracing || F.tracing) && (active || !dry));
@@ -205,10 +211,10 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
             } else if (n_wait == 0u) {
                 break;   // nothing in flight, nothing parked, nothing left to take
             }
-            // ---- transition pass: lanes whose level has ended, lanes without a pixel -----------------------------------------
+            // ---- transition pass: lanes whose level has ended, lanes without a path -------------------------------------------
             const bool mine = !(S.tracing || F.tracing) && active;
             if (COUNT) { d_pass++; d_pl += (uint32_t)__popcll(__ballot(mine)); }
-            bool begin_level = false, new_sample = false;
+            bool begin_level = false;
             float sfx = 0, sfy = 0, sfz = 0;      // surface the next level stands on
             uint32_t snormal = 0;
             if (mine) {
@@ -235,14 +241,14 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
                         L = vadd(acc, light2);
                     }
                     const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
-                    sumx = sumx + light.x; sumy = sumy + light.y; sumz = sumz + light.z;   // samples in order (k_accumulate_paths)
-                    samp++;
-                    if (samp < spp) new_sample = true;
-                    else {
-                        const PixelId pix = pixel_of_local(f, n0lp & 0x0FFFFFFFu);
-                        store_lighting(pl, pix.out_index, v3(sumx, sumy, sumz), f.spp);
-                        active = false;
+                    const uint32_t lp = n0lp & 0x0FFFFFFFu;
+                    if (spp == 1u) {
+                        const PixelId pix = pixel_of_local(f, lp);
+                        store_lighting(pl, pix.out_index, v3(0.0f + light.x, 0.0f + light.y, 0.0f + light.z), f.spp);
+                    } else {
+                        a.pl[(size_t)lp * spp + samp] = PathLight{light.x, light.y, light.z};
                     }
+                    active = false;
                 } else {
                     uint32_t material = 0;
                     if (fkind == PX_HIT && (LRZ || F.valid)) material = sc.mat[F.vox];
@@ -257,39 +263,38 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
                     level++; begin_level = true;
                 }
             }
-            // lanes without a pixel take the next ones of the queue
+            // lanes without a path take the next items
             if (!dry) {
                 const uint64_t want = __ballot(!active);
                 if (want) {
                     uint32_t base = 0;
                     if (lane == 0u) base = atomicAdd(&s_qhead, (uint32_t)__popcll(want));
                     base = __builtin_amdgcn_readfirstlane(base);
-                    const uint32_t avail = base < qtotal ? qtotal - base : 0u;
+                    const uint32_t avail = base < nitems ? nitems - base : 0u;
                     if (avail < (uint32_t)__popcll(want)) dry = true;   // (the head only grows: nothing will be left for a later pass either)
                     if (!active) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
                         if (rank < avail) {
-                            const float4 e = s_queue[base + rank];
-                            p0x = e.x; p0y = e.y; p0z = e.z; n0lp = __float_as_uint(e.w);
-                            active = true; samp = 0; sumx = sumy = sumz = 0.0f;
-                            new_sample = true;
+                            const uint32_t w = base + rank;
+                            samp = spp == 1u ? 0u : w / qtotal;
+                            const float4 e = s_queue[spp == 1u ? w : w - samp * qtotal];
+                            n0lp = __float_as_uint(e.w);
+                            active = true;
+                            // noise_offset of this sample (:298-304) and its noise_value texel (:324, :336).  The bytes are exact
+                            // integers in float and the per-level offset (level-1) * 2/512 never reaches the next texel, so one integer
+                            // lookup serves every level (tests/test_math_contract.py::test_noise_value_texel_is_level_independent)
+                            const PixelId pix = pixel_of_local(f, n0lp & 0x0FFFFFFFu);
+                            const uint32_t wgx8 = owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE, wgy8 = owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE;
+                            const uint32_t seed = (f.seed + samp) % (uint32_t)RT_NOISE_BYTES;
+                            const uint32_t by = seed / RT_NOISE_SIZE;
+                            const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
+                            const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
+                            nvtex = sc.noise[ty * RT_NOISE_SIZE + tx];
+                            sfx = e.x; sfy = e.y; sfz = e.z; snormal = n0lp >> 28;   // the pixel's primary hit: the surface every sample starts from
+                            level = 1; sunbits = 0; begin_level = true;
                         }
                     }
                 }
-            }
-            if (new_sample) {
-                // noise_offset of this sample (:298-304) and its noise_value texel (:324, :336).  The bytes are exact integers in
-                // float and the per-level offset (level-1) * 2/512 never reaches the next texel, so one integer lookup serves
-                // every level (tests/test_math_contract.py::test_noise_value_texel_is_level_independent)
-                const PixelId pix = pixel_of_local(f, n0lp & 0x0FFFFFFFu);
-                const uint32_t wgx8 = owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE, wgy8 = owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE;
-                const uint32_t seed = (f.seed + samp) % (uint32_t)RT_NOISE_BYTES;
-                const uint32_t by = seed / RT_NOISE_SIZE;
-                const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
-                const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
-                nvtex = sc.noise[ty * RT_NOISE_SIZE + tx];
-                sfx = p0x; sfy = p0y; sfz = p0z; snormal = n0lp >> 28;
-                level = 1; sunbits = 0; begin_level = true;
             }
             // both rays of a level (:324-330 / :336-342): shadow ray and diffuse ray from the tables
             if (begin_level) {
@@ -313,6 +318,22 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
                 }
                 dda_arm<LOGR, LRZ, COUNT, true, SWZ>(S, -S.ndx, -S.ndy, -S.ndz, sfx, sfy, sfz, ok, vox0, 0u, f, half, nullptr, sc, c_border, s_swz);
                 dda_arm<LOGR, LRZ, COUNT, true, SWZ>(F, -F.ndx, -F.ndy, -F.ndz, sfx, sfy, sfz, ok, vox0, 0u, f, half, nullptr, sc, c_border, s_swz);
+            }
+        }
+        // ---- more than one sample per pixel: the workgroup's ordered sums -------------------------------------------------------
+        if (spp != 1u) {
+            __threadfence();
+            __syncthreads();   // every path of the workgroup's pixels has ended and its record is written (qtotal and spp are workgroup-uniform)
+            for (uint32_t e = threadIdx.x; e < qtotal; e += kFrameWg) {
+                const uint32_t lp = __float_as_uint(s_queue[e].w) & 0x0FFFFFFFu;
+                const PathLight* rec = a.pl + (size_t)lp * spp;
+                float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+                for (uint32_t smp = 0; smp < spp; smp++) {
+                    const PathLight l = rec[smp];
+                    sx = sx + l.x; sy = sy + l.y; sz = sz + l.z;
+                }
+                const PixelId pix = pixel_of_local(f, lp);
+                store_lighting(pl, pix.out_index, v3(sx, sy, sz), f.spp);
             }
         }
     }
@@ -355,18 +376,25 @@ static void launch_frame_logr(const Scene& sc, const Frame& f, const Planes& pl,
 hipError_t launch_frame(const Scene& sc, const Frame& f, const Planes& pl, FrameArgs a, bool count, int num_cus, hipStream_t st) {
     if (f.ntiles_local <= 0) return hipSuccess;
     if (!launch_frame_ok(f)) return hipErrorInvalidValue;
-    // Tiles per wave: as many as it takes for ALL workgroups to be resident at once — five waves per SIMD at this kernel's register
-    // count — so that no workgroup starts late; a wave then refills its lanes from the workgroup's queue instead of leaving them idle
-    // while a tile's longest path finishes.  One for frames of up to 20 x CUs tiles (512 x 512 pixels on 256 CUs), at most
-    // kFrameMaxTilesPerWave (measured, ms per frame with 2 / 3 / 4 tiles: 1280 x 720 0.182 / 0.144 / 0.155, 1920 x 1080 0.323 / 0.293 / 0.271).
+    // Tiles per workgroup (four waves, which share the queue of the tiles' pixels): as many as it takes for ALL workgroups to be
+    // resident at once — five waves per SIMD at this kernel's register count — so that no workgroup starts late; a wave then refills
+    // its lanes from the workgroup's queue instead of leaving them idle while a tile's longest path finishes.  One sample per pixel:
+    // whole tiles per wave, 1 ... kFrameMaxTilesPerWave (frames of up to 20 x CUs tiles, 512 x 512 pixels on 256 CUs, have one;
+    // measured, ms per frame with 2 / 3 / 4 tiles per wave: 1280 x 720 0.182 / 0.144 / 0.155, 1920 x 1080 0.323 / 0.293 / 0.271).
+    // More samples: a tile is spp times the paths, so small frames get FEWER tiles per workgroup than it has waves (down to one: the
+    // other three waves skip phase A and share the paths) until the waves fill the GPU.
     const uint32_t ntiles = (uint32_t)f.ntiles_local, resident = 20u * (uint32_t)(num_cus > 0 ? num_cus : 256);
-    uint32_t k = a.tiles_per_wave ? a.tiles_per_wave : (ntiles + resident - 1u) / resident;
-    if (k < 1u) k = 1u;
-    if (k > kFrameMaxTilesPerWave) k = kFrameMaxTilesPerWave;
-    a.tiles_per_wave = k;
+    uint32_t tpg = a.tiles_per_group;
+    if (tpg == 0u) {
+        if (f.spp == 1) tpg = kFrameWgWaves * ((ntiles + resident - 1u) / resident);
+        else tpg = (kFrameWgWaves * ntiles + resident - 1u) / resident;
+    }
+    if (tpg < 1u) tpg = 1u;
+    if (tpg > kFrameWgWaves * kFrameMaxTilesPerWave) tpg = kFrameWgWaves * kFrameMaxTilesPerWave;
+    a.tiles_per_group = tpg;
     static const bool pair_a = getenv("RT_FRAME_PAIR_A") == nullptr || atoi(getenv("RT_FRAME_PAIR_A")) != 0;
     a.pair_a = pair_a ? 1u : 0u;
-    const dim3 grid((ntiles + kFrameWgWaves * k - 1u) / (kFrameWgWaves * k));
+    const dim3 grid((ntiles + tpg - 1u) / tpg);
     if (a.threshold < 1u || a.threshold > 64u) a.threshold = 44u;   // parked lanes per pass: 20 0.167 ms on the reference frame, 28 0.166, 40 0.162, 48 0.161, 56 0.166
     if (f.logr == 8) launch_frame_logr<8>(sc, f, pl, a, count, grid, st);
     else if (f.logr == 9) launch_frame_logr<9>(sc, f, pl, a, count, grid, st);

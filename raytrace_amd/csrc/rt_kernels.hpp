@@ -87,10 +87,11 @@ struct PersistArgs {
 // k_frame (rt_frame.hip): the whole frame in one launch — primary rays, every sample's paths, the planes — for frames with little work
 struct FrameArgs {
     uint32_t threshold;         // parked lanes per wave that trigger a transition pass (1..64; 0 = the default)
-    uint32_t tiles_per_wave;    // 0 = chosen by launch_frame from the frame's size (RT_FRAME_TILES overrides)
+    uint32_t tiles_per_group;   // tiles of a (four-wave) workgroup; 0 = chosen by launch_frame from the frame's size and spp (RT_FRAME_TILES overrides)
     uint32_t pair_a;            // set by launch_frame: phase A walks two tiles at a time, one per ray slot (RT_FRAME_PAIR_A=0: one)
     const float4* sun_lut;      // as PersistArgs
     const float4* dif_lut;
+    PathLight* pl;              // spp > 1: [local pixel * spp + sample] light of each path, summed in sample order by the pixel's workgroup
     DevCounters* counters;
     unsigned long long* dbg_waves;   // counting build, diagnostics: four words per tile (null: none)
 };

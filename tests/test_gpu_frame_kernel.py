@@ -48,21 +48,24 @@ def _check(mats, mine, noise, u, W, H, spp, depth, region=256, **kw):
     (8, 8, 1, 2),         # one tile: one wave of a four-wave workgroup has work
     (328, 200, 1, 2),     # 1025 tiles: a last workgroup with one tile
     (96, 96, 2, 8),       # the deepest frame the kernel takes (albedo stack: seven LDS rows)
+    (64, 48, 17, 3),      # more samples than a workgroup has waves: a pixel's paths run on many lanes, its sum is taken in sample order
+    (40, 24, 64, 2),      # 15 tiles, 64 samples: one workgroup's queue handed out 64 times over
 ])
 def test_frame_kernel_matches_oracle(procedural_region, blue_noise, W, H, spp, depth):
     mats, mine = procedural_region
     _check(mats, mine, blue_noise, _uniforms(seed=1), W, H, spp, depth)
 
 
-@pytest.mark.parametrize("tiles_per_wave", ["1", "2", "3", "4"])
-def test_frame_kernel_tiles_per_wave_and_threshold_do_not_change_results(procedural_region, blue_noise, tiles_per_wave, monkeypatch):
-    """RT_FRAME_TILES (tiles a wave walks before the workgroup's queue is complete) and RT_FRAME_THRESHOLD (parked lanes per pass)
-    are scheduling only.  704 x 400 = 4400 tiles: with four tiles per wave 275 workgroups, the last tiles of a wave past the end."""
-    monkeypatch.setenv("RT_FRAME_TILES", tiles_per_wave)
-    monkeypatch.setenv("RT_FRAME_THRESHOLD", {"1": "1", "2": "64", "3": "17", "4": "40"}[tiles_per_wave])
+@pytest.mark.parametrize("group_tiles", ["1", "3", "4", "7", "8", "13", "16"])
+def test_frame_kernel_tiles_per_group_and_threshold_do_not_change_results(procedural_region, blue_noise, group_tiles, monkeypatch):
+    """RT_FRAME_GROUP_TILES (tiles of a four-wave workgroup: fewer than waves — some waves skip the primary phase and only share the
+    paths —, whole tiles per wave, or a ragged deal) and RT_FRAME_THRESHOLD (parked lanes per pass) are scheduling only.  704 x 400 =
+    4400 tiles: the last workgroup's tile indices run past the end for most values."""
+    monkeypatch.setenv("RT_FRAME_GROUP_TILES", group_tiles)
+    monkeypatch.setenv("RT_FRAME_THRESHOLD", {"1": "1", "3": "64", "4": "17", "7": "40", "8": "5", "13": "33", "16": "44"}[group_tiles])
     mats, mine = procedural_region
     u = _uniforms(origin=(100.0, 100.0, 60.0), heading=-2.0, pitch=-0.1, sun=0.7, seed=23)
-    _check(mats, mine, blue_noise, u, 704, 400, 2, 3)
+    _check(mats, mine, blue_noise, u, 704, 400, 2 if int(group_tiles) % 2 else 1, 3)
 
 
 @pytest.mark.parametrize("pose", [
@@ -123,8 +126,8 @@ def test_frame_kernel_far_window_reaches_the_loop_limit(native_built, blue_noise
 
 
 def test_the_reference_frame_runs_on_the_frame_kernel_by_default(procedural_region, blue_noise):
-    """RT_KERNEL_DEFAULT: one-sample frames of fewer than 2.5 M pixels — the reference's 1024 x 1024 — run on k_frame, larger
-    one-sample frames and every multi-sample frame on the persistent kernels.  The whole 1024 x 1024 frame against the oracle
+    """RT_KERNEL_DEFAULT: one-sample frames of fewer than 2.5 M pixels — the reference's 1024 x 1024 — and multi-sample frames of fewer
+    than 1.5 M pixel-sample-levels run on k_frame, everything larger on the persistent kernels.  The whole 1024 x 1024 frame against the oracle
     (two frames drawn: the second must not depend on anything the first left behind), counters included."""
     mats, mine = procedural_region
     W = H = 1024
@@ -133,8 +136,8 @@ def test_the_reference_frame_runs_on_the_frame_kernel_by_default(procedural_regi
     gpu, gcn = _render_frame_kernel(mats, mine, blue_noise, u, W, H, 1, 2, frames=2, kernel=abi.RT_KERNEL_DEFAULT)
     _compare(gpu, cpu)
     assert gcn.as_dict() == _cached_counters(mats, mine, blue_noise, u, W, H, 1, 2, ccn)
-    for (w, h, spp, want) in ((2304, 1152, 1, abi.RT_KERNEL_PERSISTENT), (256, 256, 2, abi.RT_KERNEL_PERSISTENT), (256, 256, 1, abi.RT_KERNEL_FRAME),
-                               (1920, 1080, 1, abi.RT_KERNEL_FRAME)):
+    for (w, h, spp, want) in ((2304, 1152, 1, abi.RT_KERNEL_PERSISTENT), (512, 512, 4, abi.RT_KERNEL_PERSISTENT), (256, 256, 2, abi.RT_KERNEL_FRAME),
+                               (256, 256, 1, abi.RT_KERNEL_FRAME), (1920, 1080, 1, abi.RT_KERNEL_FRAME)):
         with render.Context(render.make_config(w, h, spp=spp, depth=2, flags=CACHE)) as ctx:
             ctx.upload_world(mats, mine)
             ctx.upload_noise(blue_noise)
@@ -143,6 +146,30 @@ def test_the_reference_frame_runs_on_the_frame_kernel_by_default(procedural_regi
             ctx.draw_frame(u)
             ctx.sync()
             assert ctx.kernel_in_use() == want
+
+
+def test_more_samples_than_the_light_records_hold_fall_back(procedural_region, blue_noise, monkeypatch):
+    """With more than one sample per pixel k_frame parks every path's light in the lane's light-record array and adds a pixel's
+    samples in order when its workgroup's paths have ended; a frame whose samples do not fit one launch's records (RT_PERSIST_BATCH
+    bounds them here) runs on the persistent kernels — and is the same frame."""
+    monkeypatch.setenv("RT_PERSIST_BATCH", "2")
+    mats, mine = procedural_region
+    u = _uniforms(seed=8)
+    W, H, spp, depth = 88, 56, 5, 3
+    cpu, _ = po.render(mats, mine, blue_noise, u, W, H, spp, depth)
+    for want_spp, want in ((5, None), (2, abi.RT_KERNEL_FRAME)):
+        cfg = render.make_config(W, H, spp=want_spp, depth=depth, kernel=abi.RT_KERNEL_FRAME, flags=CACHE)
+        with render.Context(cfg) as ctx:
+            ctx.upload_world(mats, mine)
+            ctx.upload_noise(blue_noise)
+            ctx.draw_frame(u)
+            ctx.sync()
+            if want is None:
+                assert ctx.kernel_in_use() in (abi.RT_KERNEL_PATHS, abi.RT_KERNEL_PERSISTENT)
+                _compare(ctx.readback_all(), cpu)
+            else:
+                assert ctx.kernel_in_use() == want
+                _compare(ctx.readback_all(), po.render(mats, mine, blue_noise, u, W, H, want_spp, depth)[0])
 
 
 def test_one_sample_frames_need_no_cache_flag(procedural_region, blue_noise):
