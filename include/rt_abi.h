@@ -102,11 +102,13 @@ typedef enum RtKernel {
                                  the step loop is branch-free; frames it does not cover (no primary cache)
                                  run on RT_KERNEL_PERSISTENT                                                     */
     /* 6 was RT_KERNEL_SEQ (three paths per lane, one ray slot each): retired in round 4 (ABI 1.2), rejected by rt_create */
-    RT_KERNEL_FRAME = 7,      /* (ABI 1.3) the whole frame in ONE launch: a wave per 8x8 tile walks the tile's primary rays and then
-                                 every sample's path of each of its pixels (sums in registers; no prepass, worklist, light records or
-                                 accumulate launch).  What RT_KERNEL_DEFAULT runs for frames with little work (the reference's own
-                                 1024 x 1024, 1 sample, depth 2).  Needs RT_FLAG_CACHE_PRIMARY (or one sample per pixel) and depth <= 8; other frames of such a
-                                 context run on RT_KERNEL_PATHS / RT_KERNEL_PERSISTENT                                          */
+    RT_KERNEL_FRAME = 7,      /* (ABI 1.3) the whole frame in ONE launch: waves walk the primary rays of 8x8 tiles and then every
+                                 sample's path of each of their workgroup's pixels (a pixel's samples added in order by its
+                                 workgroup; no prepass, worklist or accumulate launch).  What RT_KERNEL_DEFAULT runs for frames
+                                 with little work: the reference's own 1024 x 1024, 1 sample, depth 2 (one-sample frames below
+                                 2.5 M pixels) and multi-sample frames below 1.5 M pixel-sample-levels.  Needs
+                                 RT_FLAG_CACHE_PRIMARY (or one sample per pixel), depth <= 8 and the frame's light records in one
+                                 launch's array; other frames of such a context run on RT_KERNEL_PATHS / RT_KERNEL_PERSISTENT  */
 } RtKernel;
 
 #define RT_FLAG_COUNTERS      0x1u  /* count rays/iterations/hits exactly (slower; for B_alg + parity)   */

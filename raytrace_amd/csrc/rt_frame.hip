@@ -15,13 +15,14 @@
 //   * phase A: a tile's 64 primary rays in lockstep (they are coherent), then the five primary-only planes — and the lighting of
 //     sky pixels — for the whole wave at once; the pixels that have paths to walk go, with their primary hit, to a queue in the
 //     workgroup's LDS (ballot-ranked, one LDS atomic per wave and tile);
-//   * phase B: a lane takes a pixel from the queue and walks its paths — all samples one after the other, a level's shadow and
-//     diffuse ray together in two slots (k_persist's machinery: rt_dda.hpp) — parks when a level's rays have ended, and when
-//     `threshold` lanes are parked the wave runs one transition pass for all of them, in which lanes whose pixel is finished take
-//     the next one of the queue.  (One tile per wave and no queue — a wave's lanes idle until the tile's longest path has ended —
-//     had 20 % of the slot-lanes of a step in flight and 410 K wave-steps on the reference's frame; the queue: 324 K.)  A
-//     pixel's samples are summed in sample order in registers (0 + l1 + l2 + ...: k_accumulate_paths' arithmetic), so there are
-//     no light records and no accumulate launch, and the lane stores the pixel's lighting itself.
+//   * phase B: a lane takes a work item — sample s of queue entry e — and walks that path, a level's shadow and diffuse ray together
+//     in two slots (k_persist's machinery: rt_dda.hpp); it parks when a level's rays have ended, and when `threshold` lanes are
+//     parked the wave runs one transition pass for all of them, in which lanes whose path is finished take the next items.  (One
+//     tile per wave and no queue — a wave's lanes idle until the tile's longest path has ended — had 20 % of the slot-lanes of a
+//     step in flight and 410 K wave-steps on the reference's frame; the queue: 324 K.)  One sample per pixel — the reference's
+//     frames — and the lane stores the pixel's lighting itself; more, and the paths' lights go to the light-record array and the
+//     workgroup adds a pixel's samples in sample order once all its paths have ended (0 + l1 + l2 + ...: k_accumulate_paths'
+//     arithmetic): no accumulate launch either way.  With many samples per pixel a workgroup gets fewer tiles than it has waves.
 //
 // Values are those of raytrace.comp under the rt_math.h contract; planes and exact counters equal the oracle's (cached
 // primaries: the primary ray reads no noise, :306-320, and is traced once per pixel).
