@@ -29,7 +29,8 @@ const size_t kBytesPerPixel[RT_BUF_COUNT] = {8, 2, 1, 4, 4, 4, 16, 16, 4, 4};
 }  // namespace
 
 constexpr size_t kCursorWords = 8 * 32;   // path cursors of the persistent kernels: one word per XCD group, each on its own 128-byte line
-// RT_KERNEL_DEFAULT: launches of at least this many pixel-samples run on k_paths, smaller ones on k_persist (measured crossover,
+// RT_KERNEL_DEFAULT: launches of at least this many pixel-samples run on k_paths, smaller ones on k_persist — unless the whole
+// frame is small enough for k_frame (kFrameCrossover, kFrameCrossoverMulti below) — (measured crossover,
 // round 3, same box: 1080p spp 1 (2.1 M) 0.351 against 0.348 ms per frame, spp 2 (4.1 M) 0.409 against 0.442; 1024^2 spp 1 0.252 against 0.229)
 constexpr uint64_t kPathsCrossover = 3ull << 20;
 // ... and ONE-sample frames of fewer pixels than this run on k_frame — the whole frame in one launch, no prepass, worklist or
