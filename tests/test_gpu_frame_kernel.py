@@ -148,6 +148,18 @@ def test_the_reference_frame_runs_on_the_frame_kernel_by_default(procedural_regi
             assert ctx.kernel_in_use() == want
 
 
+def test_c2_primary_rays_only_at_full_size(procedural_region, blue_noise):
+    """BASELINE.json config 2 — 1920 x 1080, one sample, primary rays only — is a k_frame frame under RT_KERNEL_DEFAULT (phase A alone:
+    no pixel enters a queue): the whole frame against the oracle, counters included, drawn twice."""
+    mats, mine = procedural_region
+    W, H = 1920, 1080
+    u = _uniforms(seed=1)
+    cpu, ccn = po.render(mats, mine, blue_noise, u, W, H, 1, 0)
+    gpu, gcn = _render_frame_kernel(mats, mine, blue_noise, u, W, H, 1, 0, flags=abi.RT_FLAG_COUNTERS, frames=2, kernel=abi.RT_KERNEL_DEFAULT)
+    _compare(gpu, cpu, gcn, ccn)
+    assert gcn.rays == gcn.rays_primary == W * H
+
+
 def test_more_samples_than_the_light_records_hold_fall_back(procedural_region, blue_noise, monkeypatch):
     """With more than one sample per pixel k_frame parks every path's light in the lane's light-record array and adds a pixel's
     samples in order when its workgroup's paths have ended; a frame whose samples do not fit one launch's records (RT_PERSIST_BATCH
