@@ -54,7 +54,11 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
     constexpr bool SWZ = RT_FRAME_SWZ != 0 && dda_uses_swz<LOGR, LRZ>();
     __shared__ uint32_t s_swz[SWZ ? 3 * kSwzStride : 1];   // swizzle tables (rt_dda.hpp)
     __shared__ uint32_t s_stack[kFrameLdsStack][kFrameWg];   // packed material of surface j+1 at level j, per lane
-    __shared__ float4 s_queue[kFrameMaxTilesPerWave * kFrameWg];   // the workgroup's non-sky pixels: primary hit, and face id << 28 | local pixel
+    // the workgroup's non-sky pixels: primary hit and — as bits of .w — face id << 28 | gl_WorkGroupID.y * 8 << 14 | gl_WorkGroupID.x * 8 (the
+    // noise_offset terms, raytrace.comp:304: the prepass' record format); and where the pixel's planes go (a path never needs its pixel's
+    // coordinates again: no division by the tile count in the pass)
+    __shared__ float4 s_queue[kFrameMaxTilesPerWave * kFrameWg];
+    __shared__ uint32_t s_qout[kFrameMaxTilesPerWave * kFrameWg];
     __shared__ uint32_t s_qtail, s_qhead;
     if (threadIdx.x < 128u) s_albedo[threadIdx.x] = (float)threadIdx.x / 127.0f;
     if (threadIdx.x == 0u) { s_qtail = 0u; s_qhead = 0u; }
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
         }
     };
     // the tile's planes, the lighting of its sky pixels, and its other pixels into the workgroup's queue
-    auto finish_primary = [&](const RaySlot2& r, const PixelId& pix, const vec3& pdir, uint32_t lp) {
+    auto finish_primary = [&](const RaySlot2& r, const PixelId& pix, const vec3& pdir) {
         bool queue = false;
         float hx = 0, hy = 0, hz = 0;
         uint32_t nrm = 0;
@@ -143,7 +147,10 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
             base = __builtin_amdgcn_readfirstlane(base);
             if (queue) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                s_queue[base + rank] = make_float4(hx, hy, hz, __uint_as_float((nrm << 28) | lp));
+                const uint32_t info = (nrm << 28) | (owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE) << 14 |
+                                      (owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE);
+                s_queue[base + rank] = make_float4(hx, hy, hz, __uint_as_float(info));
+                s_qout[base + rank] = pix.out_index;
             }
         }
     };
@@ -169,8 +176,8 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
             if (F.tracing) advance(F, stF);
             if (S.tracing) advance(S, stS);
         }
-        finish_primary(F, pix0, pdir0, lp0);
-        if (two) finish_primary(S, pix1, pdir1, lp1);
+        finish_primary(F, pix0, pdir0);
+        if (two) finish_primary(S, pix1, pdir1);
     }
     S.tracing = false;
     F.tracing = false;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
         const uint32_t spp = (uint32_t)f.spp;
         const uint32_t nitems = qtotal * spp;   // <= 1024 * spp (the host keeps pixel-samples per frame far below 2^31)
         bool active = false, dry = false;   // active: the lane holds a path; dry (wave-uniform): every item has been handed out
-        uint32_t n0lp = 0;                  // the path's pixel: face id of its primary hit << 28 | local pixel
+        uint32_t oidx = 0;                  // where the path's pixel's planes go (PixelId::out_index; also its row in the light-record array)
         uint32_t level = 0, sunbits = 0, samp = 0, nvtex = 0;
         uint32_t dif_entry = 0xFFFFFFFFu, sun_entry = 0xFFFFFFFFu;   // table entries held by F's / S's direction registers
         for (;;) {
@@ -242,13 +249,8 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
                         L = vadd(acc, light2);
                     }
                     const vec3 light = vadd(v3(0.0f, 0.0f, 0.0f), L);
-                    const uint32_t lp = n0lp & 0x0FFFFFFFu;
-                    if (spp == 1u) {
-                        const PixelId pix = pixel_of_local(f, lp);
-                        store_lighting(pl, pix.out_index, v3(0.0f + light.x, 0.0f + light.y, 0.0f + light.z), f.spp);
-                    } else {
-                        a.pl[(size_t)lp * spp + samp] = PathLight{light.x, light.y, light.z};
-                    }
+                    if (spp == 1u) store_lighting(pl, oidx, v3(0.0f + light.x, 0.0f + light.y, 0.0f + light.z), f.spp);
+                    else a.pl[(size_t)oidx * spp + samp] = PathLight{light.x, light.y, light.z};
                     active = false;
                 } else {
                     uint32_t material = 0;
@@ -278,20 +280,21 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
                         if (rank < avail) {
                             const uint32_t w = base + rank;
                             samp = spp == 1u ? 0u : w / qtotal;
-                            const float4 e = s_queue[spp == 1u ? w : w - samp * qtotal];
-                            n0lp = __float_as_uint(e.w);
+                            const uint32_t qe = spp == 1u ? w : w - samp * qtotal;
+                            const float4 e = s_queue[qe];
+                            oidx = s_qout[qe];
                             active = true;
                             // noise_offset of this sample (:298-304) and its noise_value texel (:324, :336).  The bytes are exact
                             // integers in float and the per-level offset (level-1) * 2/512 never reaches the next texel, so one integer
                             // lookup serves every level (tests/test_math_contract.py::test_noise_value_texel_is_level_independent)
-                            const PixelId pix = pixel_of_local(f, n0lp & 0x0FFFFFFFu);
-                            const uint32_t wgx8 = owning_workgroup((uint32_t)pix.px) * RT_SHADER_GROUP_SIZE, wgy8 = owning_workgroup((uint32_t)pix.py) * RT_SHADER_GROUP_SIZE;
+                            const uint32_t info = __float_as_uint(e.w);
+                            const uint32_t wgx8 = info & 0x3FFFu, wgy8 = (info >> 14) & 0x3FFFu;
                             const uint32_t seed = (f.seed + samp) % (uint32_t)RT_NOISE_BYTES;
                             const uint32_t by = seed / RT_NOISE_SIZE;
                             const uint32_t nb = sc.noise[(by > 511u ? 511u : by) * RT_NOISE_SIZE + seed % RT_NOISE_SIZE];
                             const uint32_t tx = ((nb & 0xFFu) + wgx8) & 511u, ty = (((nb >> 8) & 0xFFu) + wgy8) & 511u;
                             nvtex = sc.noise[ty * RT_NOISE_SIZE + tx];
-                            sfx = e.x; sfy = e.y; sfz = e.z; snormal = n0lp >> 28;   // the pixel's primary hit: the surface every sample starts from
+                            sfx = e.x; sfy = e.y; sfz = e.z; snormal = info >> 28;   // the pixel's primary hit: the surface every sample starts from
                             level = 1; sunbits = 0; begin_level = true;
                         }
                     }
@@ -326,15 +329,14 @@ __global__ __launch_bounds__(kFrameWg, RT_FRAME_WAVES_PER_SIMD) void k_frame(Sce
             __threadfence();
             __syncthreads();   // every path of the workgroup's pixels has ended and its record is written (qtotal and spp are workgroup-uniform)
             for (uint32_t e = threadIdx.x; e < qtotal; e += kFrameWg) {
-                const uint32_t lp = __float_as_uint(s_queue[e].w) & 0x0FFFFFFFu;
-                const PathLight* rec = a.pl + (size_t)lp * spp;
+                const uint32_t out = s_qout[e];
+                const PathLight* rec = a.pl + (size_t)out * spp;
                 float sx = 0.0f, sy = 0.0f, sz = 0.0f;
                 for (uint32_t smp = 0; smp < spp; smp++) {
                     const PathLight l = rec[smp];
                     sx = sx + l.x; sy = sy + l.y; sz = sz + l.z;
                 }
-                const PixelId pix = pixel_of_local(f, lp);
-                store_lighting(pl, pix.out_index, v3(sx, sy, sz), f.spp);
+                store_lighting(pl, out, v3(sx, sy, sz), f.spp);
             }
         }
     }

@@ -91,7 +91,7 @@ struct FrameArgs {
     uint32_t pair_a;            // set by launch_frame: phase A walks two tiles at a time, one per ray slot (RT_FRAME_PAIR_A=0: one)
     const float4* sun_lut;      // as PersistArgs
     const float4* dif_lut;
-    PathLight* pl;              // spp > 1: [local pixel * spp + sample] light of each path, summed in sample order by the pixel's workgroup
+    PathLight* pl;              // spp > 1: [pixel's out_index * spp + sample] light of each path, summed in sample order by the pixel's workgroup
     DevCounters* counters;
     unsigned long long* dbg_waves;   // counting build, diagnostics: four words per tile (null: none)
 };
